@@ -1,0 +1,221 @@
+/*
+ * seld_hip.h -- C ABI of the MI355X (gfx950) DualQ-SELD-TCN hot path.
+ *
+ * The reference (AuroraEchos/Sound-Event-Localization-and-Detection) has no FFI of its own:
+ * its seam is the Python call into ATen.  Every entry point below
+ * names the reference call it stands in for.  Conventions, all entry points:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer borrowed for the call;
+ *   - tensors are contiguous fp32, NCHW / NCT, hypercomplex components component-major
+ *     along the channel axis;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises,
+ *     nothing allocates (workspaces are caller-provided), nothing throws;
+ *   - return value 0 = success, negative = SELD_E* code below.
+ */
+#ifndef SELD_HIP_H
+#define SELD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SELD_OK            0
+#define SELD_EINVAL       -1   /* bad descriptor (rank, channel divisibility, groups != 1 ...)      */
+#define SELD_EWORKSPACE   -2   /* workspace too small                                              */
+#define SELD_ELAUNCH      -3   /* hipLaunch reported an error (see seld_last_hip_error)            */
+#define SELD_EUNSUPPORTED -4   /* valid request this build has no kernel for                       */
+
+/* version / capability */
+int         seld_abi_version(void);          /* bumps on any signature change                      */
+const char* seld_build_arch(void);           /* "gfx950"                                           */
+int         seld_last_hip_error(void);       /* last hipError_t seen by a launch in this thread    */
+
+/* ------------------------------------------------------------------------------------------
+ * Hypercomplex convolution.  Replaces quaternion_conv (quaternion_ops.py:125-147),
+ * dual_quaternion_conv (dual_quaternion_ops.py:111-153) and the real F.conv1d/2d of the
+ * domain='R' model (model.py:81-86,106-107,185,198,276).  The kernels read the 1/4/8
+ * COMPONENT weight tensors (Cout/A, Cin/A, kh, kw) directly and apply the Hamilton signs
+ * while staging into LDS; the expanded (Cout, Cin) matrix never exists in memory.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct seld_conv_desc {
+    int32_t algebra;     /* 1 = real, 4 = quaternion, 8 = dual quaternion                       */
+    int32_t ndim;        /* 1 (NCT) or 2 (NCHW); for ndim == 1 use in[0] = k[0] = 1 etc.         */
+    int32_t N, Cin, Cout;
+    int32_t in[2];       /* input  H, W  (T in in[1] for 1-D)                                   */
+    int32_t k[2];        /* kernel kh, kw                                                       */
+    int32_t stride[2];
+    int32_t pad[2];
+    int32_t dil[2];      /* the reference spells the argument `dilatation`                       */
+    int32_t groups;      /* only 1 is supported (the reference never passes anything else)      */
+} seld_conv_desc;
+
+/* epilogue flags for seld_hc_conv_fwd_ex */
+#define SELD_EPI_NONE        0
+#define SELD_EPI_ACCUMULATE  1   /* y += conv(x)   (skip-connection running sum, model.py:210-212) */
+#define SELD_EPI_ADD         2   /* y = conv(x) + addend  (x + conv2_residual(y), model.py:132)    */
+#define SELD_EPI_STATS       4   /* also atomically accumulate per-channel sum / sum-of-squares
+                                    of the stored result into stats[0:Cout] / stats[Cout:2*Cout] */
+
+int seld_hc_conv_out_shape(const seld_conv_desc* d, int32_t out[2]);
+
+int seld_hc_conv_fwd(const seld_conv_desc* d, const float* x, const float* const w[8],
+                     const float* bias /* nullable, (Cout) */, float* y, void* stream);
+
+int seld_hc_conv_fwd_ex(const seld_conv_desc* d, const float* x, const float* const w[8],
+                        const float* bias, float* y, int32_t epilogue,
+                        const float* addend /* SELD_EPI_ADD */, float* stats /* SELD_EPI_STATS, pre-zeroed */,
+                        void* stream);
+
+/* dx = conv_transpose(dy, W)   (autograd of the F.convNd call at quaternion_ops.py:147) */
+int seld_hc_conv_bwd_data(const seld_conv_desc* d, const float* dy, const float* const w[8],
+                          float* dx, void* stream);
+
+/* dw[c] (component gradients, same shapes as w[c]) and dbias (nullable).  The Hamilton fold
+ * (sum of the signed blocks that share a component) is done on device. */
+size_t seld_hc_conv_bwd_weight_workspace(const seld_conv_desc* d);
+int seld_hc_conv_bwd_weight(const seld_conv_desc* d, const float* x, const float* dy,
+                            float* const dw[8], float* dbias /* nullable */,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hypercomplex / real linear  y[rows, out] = x[rows, in] @ M + b.
+ *   SELD_LIN_REAL   : torch.nn.Linear, weight (out, in)                 (model.py:23,439,454,458)
+ *   SELD_LIN_QUAT   : quaternion_linear, weights (in/4, out/4)          (quaternion_ops.py:299-327)
+ *   SELD_LIN_DUALQ  : dual_quaternion_linear, weights (in/8, out/8), the TRANSPOSED block
+ *                     arrangement of dual_quaternion_ops.py:170-188
+ * ------------------------------------------------------------------------------------------ */
+#define SELD_LIN_REAL   1
+#define SELD_LIN_QUAT   4
+#define SELD_LIN_DUALQ  8
+
+int seld_hc_linear_fwd(int32_t kind, int32_t rows, int32_t in_features, int32_t out_features,
+                       const float* x, const float* const w[8], const float* bias, float* y, void* stream);
+int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_features, int32_t out_features,
+                       const float* x, const float* dy, const float* const w[8],
+                       float* dx /* nullable */, float* const dw[8], float* dbias /* nullable */,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm (torch.nn.BatchNorm1d/2d at model.py:88-92,279; eps 1e-5, momentum 0.1) fused
+ * with the activation that follows it in the reference graph.
+ * x is (N, C, S) with S = prod(spatial).
+ * ------------------------------------------------------------------------------------------ */
+#define SELD_ACT_NONE    0
+#define SELD_ACT_RELU    1
+#define SELD_ACT_TANH    2
+#define SELD_ACT_SIGMOID 3
+
+/* stats[0:C] = sum, stats[C:2C] = sum of squares (accumulated atomically; caller pre-zeroes) */
+int seld_channel_stats(const float* x, int32_t N, int32_t C, int32_t S, float* stats, void* stream);
+
+/* from raw sums: mean/invstd (saved for backward) and the running-stat update (train mode) */
+int seld_bn_finalize(const float* stats, int32_t C, int64_t count, float eps, float momentum,
+                     float* mean, float* invstd, float* running_mean /* nullable */,
+                     float* running_var /* nullable */, void* stream);
+
+/* y = act(gamma * (x - mean) * invstd + beta) */
+int seld_bn_act_fwd(const float* x, int32_t N, int32_t C, int32_t S, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, int32_t act, float* y, void* stream);
+
+/* backward of the above in two passes:
+ *   reduce: dgamma[c] = sum dz * xhat, dbeta[c] = sum dz, with dz = dy * act'(y)
+ *   apply : dx = gamma * invstd * (dz - dbeta/M - xhat * dgamma/M)   (train: batch statistics)
+ *           dx = gamma * invstd * dz                                  (eval: running statistics) */
+int seld_bn_act_bwd_reduce(const float* dy, const float* x, const float* y, int32_t N, int32_t C, int32_t S,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           int32_t act, float* dgamma_dbeta /* (2C) pre-zeroed */, void* stream);
+int seld_bn_act_bwd_apply(const float* dy, const float* x, const float* y, int32_t N, int32_t C, int32_t S,
+                          const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          int32_t act, const float* dgamma_dbeta, int32_t train, float* dx, void* stream);
+
+/* gated activation of the residual block (model.py:121-128):
+ *   y = tanh(bn_f(yf)) * sigmoid(bn_g(yg)) * mask[n, c]      (mask nullable = Dropout1d channel mask,
+ *                                                            already scaled by 1/(1-p))            */
+int seld_gate_fwd(const float* yf, const float* yg, int32_t N, int32_t C, int32_t S,
+                  const float* mean_f, const float* invstd_f, const float* gamma_f, const float* beta_f,
+                  const float* mean_g, const float* invstd_g, const float* gamma_g, const float* beta_g,
+                  const float* mask, float* y, void* stream);
+/* backward: reduce pass accumulates (dgamma_f, dbeta_f, dgamma_g, dbeta_g) into red[4C] (pre-zeroed),
+ * apply pass writes dyf, dyg */
+int seld_gate_bwd_reduce(const float* dy, const float* yf, const float* yg, int32_t N, int32_t C, int32_t S,
+                         const float* mean_f, const float* invstd_f, const float* gamma_f, const float* beta_f,
+                         const float* mean_g, const float* invstd_g, const float* gamma_g, const float* beta_g,
+                         const float* mask, float* red, void* stream);
+int seld_gate_bwd_apply(const float* dy, const float* yf, const float* yg, int32_t N, int32_t C, int32_t S,
+                        const float* mean_f, const float* invstd_f, const float* gamma_f, const float* beta_f,
+                        const float* mean_g, const float* invstd_g, const float* gamma_g, const float* beta_g,
+                        const float* mask, const float* red, int32_t train, float* dyf, float* dyg, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / pooling / dropout   (torch.nn.ReLU/Tanh/MaxPool/Dropout at model.py:175-202,
+ * 280-282, 449-451)
+ * ------------------------------------------------------------------------------------------ */
+int seld_act_fwd(const float* x, int64_t n, int32_t act, float* y, void* stream);
+int seld_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float* dx, void* stream);
+
+/* max pool over windows (ph, pw), stride = window, floor mode; x (NC, H, W) -> y (NC, H/ph, W/pw).
+ * idx (uint8, nullable) receives the argmax position inside the window (row-major), as torch
+ * keeps indices for backward. */
+int seld_maxpool_fwd(const float* x, int64_t NC, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                     float* y, uint8_t* idx, void* stream);
+int seld_maxpool_bwd(const float* dy, const uint8_t* idx, int64_t NC, int32_t H, int32_t W,
+                     int32_t ph, int32_t pw, float* dx, void* stream);
+
+/* dropout with a Philox-4x32-10 counter RNG: element i is kept iff u(seed, offset + i/4)[i%4] >= p.
+ * `per_channel` (Dropout1d): one decision per (n, c) row of length S.  y = x * keep / (1 - p). */
+int seld_dropout_fwd(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, float* y, void* stream);
+int seld_dropout_mask_rows(int64_t rows, float p, uint64_t seed, uint64_t offset, float* mask, void* stream);
+
+/* y = a + b ; y += b */
+int seld_add(const float* a, const float* b, int64_t n, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head self attention core (model.py:39-48): out = softmax(q k^T / sqrt(hd)) v,
+ * flash style (the T x T energy tensor is never materialised).
+ * q, k, v, out: (N, T, H*hd) with head h at channels [h*hd, (h+1)*hd)  (model.py:35-37).
+ * lse (N, H, T): log-sum-exp of the scaled scores, saved for backward.
+ * ------------------------------------------------------------------------------------------ */
+int seld_mha_fwd(const float* q, const float* k, const float* v, int32_t N, int32_t T, int32_t H, int32_t hd,
+                 float* out, float* lse, void* stream);
+int seld_mha_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                 const float* lse, int32_t N, int32_t T, int32_t H, int32_t hd,
+                 float* dq, float* dk, float* dv, void* stream);
+
+/* (N, C, T) <-> (N, T, C) transposes around the attention block (model.py:220-222) */
+int seld_transpose_nct_ntc(const float* x, int32_t N, int32_t C, int32_t T, float* y, void* stream);
+int seld_transpose_ntc_nct(const float* x, int32_t N, int32_t T, int32_t C, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss (train.py:186-204): loss = w_sed * BCE(sigmoid(sed_logits), t_sed) + w_doa * MSE(tanh(doa_logits), t_doa)
+ * target is (rows, n_sed + n_doa) row-major as produced by the preprocessing (train.py:191-192).
+ * Writes sed = sigmoid(logits), doa = tanh(logits), loss[0] (pre-zeroed) and, if non-null, the
+ * gradients w.r.t. the LOGITS scaled by grad_scale.
+ * ------------------------------------------------------------------------------------------ */
+int seld_loss_fwd_bwd(const float* sed_logits, const float* doa_logits, const float* target,
+                      int64_t rows, int32_t n_sed, int32_t n_doa, float w_sed, float w_doa,
+                      float* sed, float* doa, float* loss, float* dsed_logits, float* ddoa_logits,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam (torch.optim.Adam defaults, train.py:502) over ONE flat fp32 buffer that holds every
+ * parameter; grads/exp_avg/exp_avg_sq are parallel flat buffers.  step is 1-based.
+ * ------------------------------------------------------------------------------------------ */
+int seld_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                   float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * STFT magnitude / phase (utility_functions.py:129-155 = scipy.signal.stft(window='hamming',
+ * boundary='zeros', padded=True) -> abs/angle -> drop DC bin -> drop last frame).
+ * x (C, L) fp32; out (C or 2C, nperseg/2, frames-1) fp32, phase channels after magnitude channels.
+ * ------------------------------------------------------------------------------------------ */
+int seld_stft_frames(int32_t L, int32_t nperseg, int32_t noverlap);   /* frames AFTER the cut */
+int seld_stft_magphase(const float* x, int32_t C, int32_t L, int32_t nperseg, int32_t noverlap,
+                       int32_t output_phase, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELD_HIP_H */

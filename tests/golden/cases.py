@@ -1,0 +1,126 @@
+"""Case tables shared by the fixture generator (make_golden.py, runs against the reference)
+and by the tests (run against the oracle and the HIP path).  Pure data + closed-form inputs;
+nothing here touches /root/reference."""
+import math
+
+import torch
+
+from oracle.seld_oracle import closed_form_input
+
+# ---------------------------------------------------------------------------------------
+# Per-op cases (set G1)
+# ---------------------------------------------------------------------------------------
+OP_CASES = [
+    # kind, x shape, Cout, kernel, stride, padding, dilation, bias
+    dict(name="q1d_k1", kind="qconv", x=(2, 16, 40), cout=24, k=(1,), stride=1, padding=0, dilation=1, bias=False),
+    dict(name="q1d_k3_d1", kind="qconv", x=(2, 16, 40), cout=32, k=(3,), stride=1, padding=1, dilation=1, bias=True),
+    dict(name="q1d_k3_d3", kind="qconv", x=(2, 16, 40), cout=32, k=(3,), stride=1, padding=3, dilation=3, bias=False),
+    dict(name="q1d_k3_d55", kind="qconv", x=(2, 8, 64), cout=16, k=(3,), stride=1, padding=55, dilation=55, bias=False),
+    dict(name="q1d_k3_s2", kind="qconv", x=(2, 8, 41), cout=8, k=(3,), stride=2, padding=0, dilation=1, bias=True),
+    dict(name="q2d_3x3", kind="qconv", x=(2, 8, 12, 20), cout=16, k=(3, 3), stride=1, padding=1, dilation=1, bias=False),
+    dict(name="dq1d_k1", kind="dqconv", x=(2, 32, 40), cout=16, k=(1,), stride=1, padding=0, dilation=1, bias=False),
+    dict(name="dq1d_k3_d1", kind="dqconv", x=(2, 16, 40), cout=32, k=(3,), stride=1, padding=1, dilation=1, bias=True),
+    dict(name="dq1d_k3_d3", kind="dqconv", x=(2, 16, 40), cout=32, k=(3,), stride=1, padding=3, dilation=3, bias=False),
+    dict(name="dq1d_k3_d55", kind="dqconv", x=(2, 16, 64), cout=16, k=(3,), stride=1, padding=55, dilation=55, bias=False),
+    dict(name="dq2d_3x3_in8", kind="dqconv", x=(2, 8, 16, 24), cout=16, k=(3, 3), stride=1, padding=1, dilation=1, bias=False),
+    dict(name="dq2d_3x3", kind="dqconv", x=(2, 16, 6, 20), cout=24, k=(3, 3), stride=1, padding=1, dilation=1, bias=True),
+    dict(name="qlin_2d", kind="qlinear", x=(5, 16), cout=24, bias=True),
+    dict(name="qlin_3d", kind="qlinear", x=(3, 4, 16), cout=8, bias=False),
+    dict(name="qlinfn_3d", kind="qlinear_fn", x=(3, 4, 16), cout=24, bias=True),
+    dict(name="dqlin_2d", kind="dqlinear", x=(5, 16), cout=24, bias=True),
+    dict(name="dqlin_3d", kind="dqlinear", x=(3, 4, 32), cout=16, bias=False),
+]
+
+
+def op_inputs(case, dtype=torch.float32):
+    """Closed-form input, component weights and bias of an op case."""
+    kind = case["kind"]
+    A = 8 if kind.startswith("dq") else 4
+    x = closed_form_input(case["x"], dtype)
+    cout = case["cout"]
+    if "conv" in kind:
+        cin = case["x"][1]
+        wshape = (cout // A, cin // A) + tuple(case["k"])
+    else:
+        cin = case["x"][-1]
+        wshape = (cin // A, cout // A)
+    numel = 1
+    for s in wshape:
+        numel *= s
+    n = torch.arange(numel, dtype=torch.float64)
+    ws = [(0.4 * torch.sin(0.37 * n + 1.3 * c + 0.2)).view(wshape).to(dtype) for c in range(A)]
+    bias = None
+    if case["bias"]:
+        bias = (0.1 * torch.cos(torch.arange(cout, dtype=torch.float64) * 0.9)).to(dtype)
+    return x, ws, bias
+
+
+def op_cotangent(y_shape, dtype=torch.float32):
+    return closed_form_input(tuple(y_shape), dtype).flip(0) * 0.5 + 0.25
+
+
+# ---------------------------------------------------------------------------------------
+# Whole-model cases (sets G2-G4)
+# ---------------------------------------------------------------------------------------
+_TINY = dict(output_classes=14, cnn_filters=[16, 16, 16], kernel_size_cnn_blocks=3,
+             pool_size=[[8, 2], [8, 2], [2, 2]], pool_time="TCN", D=[10], dilation_mode="fibonacci",
+             G=32, U=16, kernel_size_dilated_conv=3, V=[16, 16], V_kernel_size=3, fc_layers=[16],
+             fc_activations="linear", fc_dropout="Last", class_overlaps=3, use_bias_conv=0,
+             use_bias_linear=1, batch_norm="BN", dropout_perc=0.0, spatial_dropout_rate=0.0,
+             freq_dim=128, time_dim=64, B=2, train=True)
+
+MODEL_CASES = [
+    dict(_TINY, name="tiny_R", domain="R", domain_classifier="R", input_channels=8,
+         full_grads=["seld_block.cnn.0.0.weight", "seld_block.tcn.ResBlocks.3.conv1_gate.weight", "sed.2.weight"]),
+    dict(_TINY, name="tiny_Q", domain="Q", domain_classifier="R", input_channels=8,
+         full_grads=["seld_block.cnn.0.0.j_weight", "seld_block.tcn.ResBlocks.9.conv1_filter.k_weight",
+                     "seld_block.tcn.attention.keys.weight"]),
+    dict(_TINY, name="tiny_Qcls", domain="Q", domain_classifier="Q", input_channels=8, use_bias_conv=1,
+         fc_activations="relu", fc_dropout="all",
+         full_grads=["sed.0.i_weight", "doa.0.bias", "seld_block.cnn.1.0.bias"]),
+    dict(_TINY, name="tiny_DQ", domain="DQ", domain_classifier="DQ", input_channels=8,
+         full_grads=["seld_block.cnn.0.0.r_weight", "seld_block.cnn.0.0.k_weight_2", "seld_block.cnn.1.0.i_weight",
+                     "seld_block.tcn.ResBlocks.5.conv1_filter.j_weight_2", "seld_block.tcn.ResBlocks.0.conv2_skip.r_weight",
+                     "seld_block.tcn.conv2.i_weight_2", "seld_block.tcn.attention.fc_out.weight",
+                     "sed.0.j_weight_2", "doa.0.r_weight", "doa.2.bias"]),
+    # config-exact frequency handling: F=256 leaves F'=2 after the CNN, so the (C, F') -> C*F'
+    # interleave of model.py:302-310 is exercised; L = 2*16 = 32 = U.
+    dict(_TINY, name="tiny_DQ_F256", domain="DQ", domain_classifier="DQ", input_channels=8, freq_dim=256, U=32,
+         time_dim=32, full_grads=["seld_block.cnn.2.0.r_weight_2", "seld_block.tcn.ResBlocks.0.conv1_gate.i_weight"]),
+    dict(_TINY, name="tiny_DQ16", domain="DQ", domain_classifier="DQ", input_channels=16,
+         full_grads=["seld_block.cnn.0.0.j_weight"]),
+    dict(_TINY, name="tiny_2stream", domain="DQ", domain_classifier="R", input_channels=16,
+         parallel_ConvTC_block="2Parallel", parallel_magphase=True,
+         full_grads=["branch_A.cnn.0.0.r_weight", "branch_B.tcn.ResBlocks.2.conv2_residual.k_weight_2", "sed.0.weight"]),
+    # config 3 widths: eval only, outputs only
+    dict(name="c3_F128", domain="DQ", domain_classifier="DQ", input_channels=8, output_classes=14,
+         cnn_filters=[192, 192, 192], kernel_size_cnn_blocks=3, pool_size=[[8, 2], [8, 2], [2, 2]], pool_time="TCN",
+         D=[10], dilation_mode="fibonacci", G=384, U=192, kernel_size_dilated_conv=3, V=[384, 384], V_kernel_size=3,
+         fc_layers=[384], fc_activations="linear", fc_dropout="Last", class_overlaps=3, use_bias_conv=0,
+         use_bias_linear=1, batch_norm="BN", dropout_perc=0.3, spatial_dropout_rate=0.5,
+         freq_dim=128, time_dim=512, B=1, train=False, taps=False),
+    dict(name="c2_F128", domain="Q", domain_classifier="R", input_channels=8, output_classes=14,
+         cnn_filters=[64, 64, 64], kernel_size_cnn_blocks=3, pool_size=[[8, 2], [8, 2], [2, 2]], pool_time="TCN",
+         D=[10], dilation_mode="fibonacci", G=128, U=64, kernel_size_dilated_conv=3, V=[128, 128], V_kernel_size=3,
+         fc_layers=[128], fc_activations="linear", fc_dropout="Last", class_overlaps=3, use_bias_conv=0,
+         use_bias_linear=1, batch_norm="BN", dropout_perc=0.3, spatial_dropout_rate=0.5,
+         freq_dim=128, time_dim=512, B=1, train=False, taps=False),
+]
+
+_NON_CTOR = {"name", "B", "train", "taps", "full_grads"}
+
+
+def model_kwargs(case):
+    return {k: v for k, v in case.items() if k not in _NON_CTOR}
+
+
+def train_target(case, dtype=torch.float32):
+    """Deterministic (B, T/8, 42 + 126) target: sparse {0,1} SED part, smooth DOA part."""
+    n_sed = int(case["output_classes"] * 3)
+    t_out = case["time_dim"] // 8
+    B = case["B"]
+    n = torch.arange(B * t_out * n_sed, dtype=torch.float64)
+    sed = (torch.sin(0.7 * n) > 0.8).to(torch.float64).view(B, t_out, n_sed)
+    n = torch.arange(B * t_out * n_sed * 3, dtype=torch.float64)
+    doa = (0.9 * torch.sin(0.013 * n)).view(B, t_out, n_sed * 3)
+    return torch.cat((sed, doa), dim=2).to(dtype)
