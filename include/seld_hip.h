@@ -92,10 +92,13 @@ int seld_hc_conv_bwd_weight(const seld_conv_desc* d, const float* x, const float
 
 int seld_hc_linear_fwd(int32_t kind, int32_t rows, int32_t in_features, int32_t out_features,
                        const float* x, const float* const w[8], const float* bias, float* y, void* stream);
+/* dx = dy @ M^T (nullable), dw[c] = folded x^T @ dy, dbias = column sums of dy (nullable).
+ * workspace: in_features * out_features floats. */
+size_t seld_hc_linear_bwd_workspace(int32_t kind, int32_t in_features, int32_t out_features);
 int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_features, int32_t out_features,
                        const float* x, const float* dy, const float* const w[8],
-                       float* dx /* nullable */, float* const dw[8], float* dbias /* nullable */,
-                       void* stream);
+                       float* dx /* nullable */, float* const dw[8] /* nullable */, float* dbias /* nullable */,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (torch.nn.BatchNorm1d/2d at model.py:88-92,279; eps 1e-5, momentum 0.1) fused
@@ -114,6 +117,10 @@ int seld_channel_stats(const float* x, int32_t N, int32_t C, int32_t S, float* s
 int seld_bn_finalize(const float* stats, int32_t C, int64_t count, float eps, float momentum,
                      float* mean, float* invstd, float* running_mean /* nullable */,
                      float* running_var /* nullable */, void* stream);
+
+/* eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps) */
+int seld_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
+                       float* mean, float* invstd, void* stream);
 
 /* y = act(gamma * (x - mean) * invstd + beta) */
 int seld_bn_act_fwd(const float* x, int32_t N, int32_t C, int32_t S, const float* mean, const float* invstd,
@@ -172,31 +179,33 @@ int seld_dropout_mask_rows(int64_t rows, float p, uint64_t seed, uint64_t offset
 int seld_add(const float* a, const float* b, int64_t n, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Multi-head self attention core (model.py:39-48): out = softmax(q k^T / sqrt(hd)) v,
- * flash style (the T x T energy tensor is never materialised).
- * q, k, v, out: (N, T, H*hd) with head h at channels [h*hd, (h+1)*hd)  (model.py:35-37).
+ * Multi-head self attention core (model.py:39-48): out = softmax(q k^T / sqrt(hd)) v, flash style
+ * (the T x T energy tensor is never materialised).
+ * q, k, v, out: (N, H*hd, T) -- the layout the 1x1 Conv1d projections of model.py:20-22 produce --
+ * with head h on channels [h*hd, (h+1)*hd) (model.py:35-37).  hd <= 64.
  * lse (N, H, T): log-sum-exp of the scaled scores, saved for backward.
  * ------------------------------------------------------------------------------------------ */
 int seld_mha_fwd(const float* q, const float* k, const float* v, int32_t N, int32_t T, int32_t H, int32_t hd,
                  float* out, float* lse, void* stream);
+size_t seld_mha_bwd_workspace(int32_t N, int32_t T, int32_t H);
 int seld_mha_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                  const float* lse, int32_t N, int32_t T, int32_t H, int32_t hd,
-                 float* dq, float* dk, float* dv, void* stream);
+                 float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, void* stream);
 
-/* (N, C, T) <-> (N, T, C) transposes around the attention block (model.py:220-222) */
+/* (N, C, T) <-> (N, T, C) transposes (the permutes of model.py:30-37, 220-222, 318) */
 int seld_transpose_nct_ntc(const float* x, int32_t N, int32_t C, int32_t T, float* y, void* stream);
 int seld_transpose_ntc_nct(const float* x, int32_t N, int32_t T, int32_t C, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Loss (train.py:186-204): loss = w_sed * BCE(sigmoid(sed_logits), t_sed) + w_doa * MSE(tanh(doa_logits), t_doa)
+ * Loss (train.py:186-204): loss = w_sed * BCELoss(sed, t_sed) + w_doa * MSELoss(doa, t_doa), mean
+ * reductions (train.py:498-499); sed/doa are the model OUTPUTS (after Sigmoid / Tanh).
  * target is (rows, n_sed + n_doa) row-major as produced by the preprocessing (train.py:191-192).
- * Writes sed = sigmoid(logits), doa = tanh(logits), loss[0] (pre-zeroed) and, if non-null, the
- * gradients w.r.t. the LOGITS scaled by grad_scale.
+ * Accumulates the scalar into loss[0] (caller pre-zeroes) and, if non-null, writes dloss/dsed and
+ * dloss/ddoa (torch.nn.BCELoss semantics: logs clamped at -100, backward denominator >= 1e-12).
  * ------------------------------------------------------------------------------------------ */
-int seld_loss_fwd_bwd(const float* sed_logits, const float* doa_logits, const float* target,
+int seld_loss_fwd_bwd(const float* sed, const float* doa, const float* target,
                       int64_t rows, int32_t n_sed, int32_t n_doa, float w_sed, float w_doa,
-                      float* sed, float* doa, float* loss, float* dsed_logits, float* ddoa_logits,
-                      void* stream);
+                      float* loss, float* dsed, float* ddoa, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Adam (torch.optim.Adam defaults, train.py:502) over ONE flat fp32 buffer that holds every
@@ -210,6 +219,7 @@ int seld_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_a
  * STFT magnitude / phase (utility_functions.py:129-155 = scipy.signal.stft(window='hamming',
  * boundary='zeros', padded=True) -> abs/angle -> drop DC bin -> drop last frame).
  * x (C, L) fp32; out (C or 2C, nperseg/2, frames-1) fp32, phase channels after magnitude channels.
+ * nperseg must be a power of two <= 512 (the reference uses 512).
  * ------------------------------------------------------------------------------------------ */
 int seld_stft_frames(int32_t L, int32_t nperseg, int32_t noverlap);   /* frames AFTER the cut */
 int seld_stft_magphase(const float* x, int32_t C, int32_t L, int32_t nperseg, int32_t noverlap,

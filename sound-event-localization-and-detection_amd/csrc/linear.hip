@@ -1,0 +1,218 @@
+// Real / quaternion / dual-quaternion linear layers on (rows, features) tensors for gfx950.
+//
+//   y[r][o] = sum_i x[r][i] * M(i, o) + b[o]
+//
+// M is the expanded real matrix of the layer; it is never built: element M(i, o) is read from the
+// component tensors with the Hamilton sign (quaternion_ops.py:310-314) or, for the dual
+// quaternion layer, the transposed block arrangement of dual_quaternion_ops.py:170-188.
+// These layers are the two classifier heads (rows = B*T/8, <= 0.2 % of the model's flops), so a
+// plain LDS-tiled fp32 VALU GEMM is used (64 x 64 tile, 4 x 4 per thread).
+#include "common.h"
+
+namespace seld {
+
+struct LinP {
+    int kind;        // 1 real, 4 quat, 8 dualq
+    int in_f, out_f;
+    int IA, OA;      // in/A, out/A
+    WPtrs w;
+};
+
+__device__ __forceinline__ float lin_elem(const LinP& p, int i, int o) {
+    if (p.kind == SELD_LIN_REAL) return p.w.p[0][(size_t)o * p.in_f + i];
+    const int a = i / p.IA, c = i - a * p.IA;
+    const int b = o / p.OA, oo = o - b * p.OA;
+    float sign;
+    int comp;
+    if (p.kind == SELD_LIN_QUAT) comp = block_comp(4, b, a, &sign);   // block (in a, out b) = table[b][a]
+    else comp = block_comp(8, a, b, &sign);                           // block (in a, out b) = table8[a][b]
+    if (comp < 0) return 0.f;
+    return sign * p.w.p[comp][(size_t)c * p.OA + oo];
+}
+
+// out[r][n] = sum_k A[r][k] * Bm(k, n)  (+ bias[n]);  TRANS=0: Bm(k,n) = M(k,n), K = in, Nn = out
+//                                                      TRANS=1: Bm(k,n) = M(n,k), K = out, Nn = in
+template <int TRANS>
+__global__ __launch_bounds__(256) void linear_gemm_kernel(const LinP p, int rows, const float* __restrict__ A,
+                                                          const float* __restrict__ bias, float* __restrict__ out) {
+    const int K = TRANS ? p.out_f : p.in_f;
+    const int Nn = TRANS ? p.in_f : p.out_f;
+    __shared__ float As[16][64 + 4];
+    __shared__ float Bs[16][64 + 4];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tr = (tid >> 4) * 4, tn = (tid & 15) * 4;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        // A tile: 64 rows x 16 k (row-major source, k contiguous)
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int r = e >> 4, k = e & 15;
+            float v = 0.f;
+            if (r0 + r < rows && k0 + k < K) v = A[(size_t)(r0 + r) * K + k0 + k];
+            As[k][r] = v;
+        }
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int n = e & 63, k = e >> 6;
+            float v = 0.f;
+            if (n0 + n < Nn && k0 + k < K) v = TRANS ? lin_elem(p, n0 + n, k0 + k) : lin_elem(p, k0 + k, n0 + n);
+            Bs[k][n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[k][tr + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[k][tn + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + tr + i, n = n0 + tn + j;
+            if (r < rows && n < Nn) out[(size_t)r * Nn + n] = acc[i][j] + (bias ? bias[n] : 0.f);
+        }
+}
+
+// dM[i][o] = sum_r x[r][i] * dy[r][o]
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int in_f, int out_f, const float* __restrict__ x,
+                                                           const float* __restrict__ dy, float* __restrict__ dM) {
+    __shared__ float Xs[16][64 + 4];
+    __shared__ float Ds[16][64 + 4];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.y * 64, o0 = blockIdx.x * 64;
+    const int ti = (tid >> 4) * 4, to = (tid & 15) * 4;
+    float acc[4][4] = {};
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int c = e & 63, r = e >> 6;
+            Xs[r][c] = (r0 + r < rows && i0 + c < in_f) ? x[(size_t)(r0 + r) * in_f + i0 + c] : 0.f;
+            Ds[r][c] = (r0 + r < rows && o0 + c < out_f) ? dy[(size_t)(r0 + r) * out_f + o0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = Xs[r][ti + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Ds[r][to + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ii = i0 + ti + i, oo = o0 + to + j;
+            if (ii < in_f && oo < out_f) dM[(size_t)ii * out_f + oo] = acc[i][j];
+        }
+}
+
+__global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, WPtrsMut dw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p.kind == SELD_LIN_REAL) {
+        if (idx >= p.in_f * p.out_f) return;
+        const int o = idx / p.in_f, i = idx - o * p.in_f;
+        dw.p[0][idx] = dM[(size_t)i * p.out_f + o];
+        return;
+    }
+    const int A = p.kind;
+    const int per = p.IA * p.OA;
+    if (idx >= per * A) return;
+    const int comp = idx / per;
+    const int rem = idx - comp * per;
+    const int c = rem / p.OA, oo = rem - c * p.OA;
+    float total = 0.f;
+    for (int a = 0; a < A; ++a)
+        for (int b = 0; b < A; ++b) {
+            float sign;
+            const int cc = (p.kind == SELD_LIN_QUAT) ? block_comp(4, b, a, &sign) : block_comp(8, a, b, &sign);
+            if (cc != comp) continue;
+            total += sign * dM[(size_t)(a * p.IA + c) * p.out_f + (size_t)b * p.OA + oo];
+        }
+    dw.p[comp][rem] = total;
+}
+
+__global__ void column_sum_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += x[(size_t)r * cols + c];
+    out[c] = s;
+}
+
+static int mk_lin(LinP& p, int kind, int in_f, int out_f, const float* const w[8]) {
+    if (kind != SELD_LIN_REAL && kind != SELD_LIN_QUAT && kind != SELD_LIN_DUALQ) return SELD_EINVAL;
+    if (in_f <= 0 || out_f <= 0 || in_f % kind || out_f % kind) return SELD_EINVAL;
+    p.kind = kind; p.in_f = in_f; p.out_f = out_f; p.IA = in_f / kind; p.OA = out_f / kind;
+    for (int i = 0; i < 8; ++i) p.w.p[i] = (w && i < kind) ? w[i] : nullptr;
+    return SELD_OK;
+}
+
+}  // namespace seld
+using namespace seld;
+
+extern "C" int seld_hc_linear_fwd(int32_t kind, int32_t rows, int32_t in_features, int32_t out_features, const float* x,
+                                  const float* const w[8], const float* bias, float* y, void* stream) {
+    LinP p{};
+    int rc = mk_lin(p, kind, in_features, out_features, w);
+    if (rc) return rc;
+    if (!x || !w || !y || rows <= 0) return SELD_EINVAL;
+    dim3 grid((out_features + 63) / 64, (rows + 63) / 64);
+    hipLaunchKernelGGL((linear_gemm_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, x, bias, y);
+    return check_launch();
+}
+
+extern "C" size_t seld_hc_linear_bwd_workspace(int32_t kind, int32_t in_features, int32_t out_features) {
+    (void)kind;
+    if (in_features <= 0 || out_features <= 0) return 0;
+    return (size_t)in_features * out_features * sizeof(float);
+}
+
+extern "C" int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_features, int32_t out_features, const float* x,
+                                  const float* dy, const float* const w[8], float* dx, float* const dw[8], float* dbias,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    LinP p{};
+    int rc = mk_lin(p, kind, in_features, out_features, w);
+    if (rc) return rc;
+    if (!dy || rows <= 0) return SELD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        if (!w) return SELD_EINVAL;
+        dim3 grid((in_features + 63) / 64, (rows + 63) / 64);
+        hipLaunchKernelGGL((linear_gemm_kernel<1>), grid, dim3(256), 0, st, p, rows, dy, (const float*)nullptr, dx);
+        rc = check_launch();
+        if (rc) return rc;
+    }
+    if (dw) {
+        if (!x) return SELD_EINVAL;
+        if (!workspace || workspace_bytes < seld_hc_linear_bwd_workspace(kind, in_features, out_features)) return SELD_EWORKSPACE;
+        dim3 grid((out_features + 63) / 64, (in_features + 63) / 64);
+        hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, st, rows, in_features, out_features, x, dy, (float*)workspace);
+        rc = check_launch();
+        if (rc) return rc;
+        WPtrsMut out{};
+        for (int i = 0; i < 8; ++i) out.p[i] = i < kind ? dw[i] : nullptr;
+        const int total = in_features * out_features / (kind == SELD_LIN_REAL ? 1 : kind);
+        hipLaunchKernelGGL(linear_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p, (const float*)workspace, out);
+        rc = check_launch();
+        if (rc) return rc;
+    }
+    if (dbias) {
+        hipLaunchKernelGGL(column_sum_kernel, dim3((out_features + 255) / 256), dim3(256), 0, st, dy, rows, out_features, dbias);
+        rc = check_launch();
+    }
+    return rc;
+}

@@ -1,0 +1,677 @@
+// BatchNorm (+ fused activations), gated activation, pooling, dropout, loss and Adam kernels
+// for gfx950.  All HBM-bound: 16-byte loads/stores along the contiguous S axis, per-channel
+// reductions by wave shuffles + one atomic per wave (guide: Appendix B "Reduction").
+#include "common.h"
+
+namespace seld {
+
+__device__ __forceinline__ float act_apply(float z, int act) {
+    switch (act) {
+        case SELD_ACT_RELU: return z > 0.f ? z : 0.f;
+        case SELD_ACT_TANH: return tanhf(z);
+        case SELD_ACT_SIGMOID: return 1.0f / (1.0f + expf(-z));
+        default: return z;
+    }
+}
+// derivative expressed through the OUTPUT y = act(z)
+__device__ __forceinline__ float act_grad_from_y(float y, int act) {
+    switch (act) {
+        case SELD_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case SELD_ACT_TANH: return 1.f - y * y;
+        case SELD_ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-channel sum / sum of squares over (N, S)
+// grid: (chunks, C); each block walks `chunk` elements of channel c's N*S index space.
+// ------------------------------------------------------------------------------------------
+constexpr int RED_CHUNK = 8192;
+
+template <typename F>
+__device__ __forceinline__ void channel_walk(int N, int C, int S, int c, F&& f) {
+    // calls f(offset_of_4_or_1_elements, count) for this block's slice of channel c
+    const long long M = (long long)N * S;
+    const long long beg = (long long)blockIdx.x * RED_CHUNK;
+    long long end = beg + RED_CHUNK;
+    if (end > M) end = M;
+    if ((S & 3) == 0) {
+        for (long long i = beg + (long long)threadIdx.x * 4; i < end; i += (long long)blockDim.x * 4) {
+            long long n = i / S;
+            int s = (int)(i - n * S);
+            f(((size_t)n * C + c) * S + s, 4);
+        }
+    } else {
+        for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+            long long n = i / S;
+            int s = (int)(i - n * S);
+            f(((size_t)n * C + c) * S + s, 1);
+        }
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void block_atomic(float (&v)[NV], float* const (&dst)[NV]) {
+    __shared__ float red[NV][4];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float s = wave_sum(v[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int k = threadIdx.x;
+        atomicAdd(dst[k], red[k][0] + red[k][1] + red[k][2] + red[k][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int N, int C, int S,
+                                                            float* __restrict__ stats) {
+    const int c = blockIdx.y;
+    float v[2] = {0.f, 0.f};
+    channel_walk(N, C, S, c, [&](size_t off, int cnt) {
+        if (cnt == 4) {
+            float4 a = *reinterpret_cast<const float4*>(x + off);
+            v[0] += (a.x + a.y) + (a.z + a.w);
+            v[1] += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+        } else {
+            float a = x[off];
+            v[0] += a;
+            v[1] += a * a;
+        }
+    });
+    float* const dst[2] = {stats + c, stats + C + c};
+    block_atomic<2>(v, dst);
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double count, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ rmean, float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = (double)stats[c] / count;
+    double var = (double)stats[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval mode: mean = running_mean, invstd = rsqrt(running_var + eps)
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    invstd[c] = 1.0f / sqrtf(rvar[c] + eps);
+}
+
+// ------------------------------------------------------------------------------------------
+// elementwise over (N, C, S) with per-channel constants
+// ------------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ void ncs_walk(long long total, int C, int S, F&& f) {
+    // grid-stride over groups of 4 (S % 4 == 0) or single elements
+    if ((S & 3) == 0) {
+        const long long groups = total >> 2;
+        for (long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; gidx < groups;
+             gidx += (long long)gridDim.x * blockDim.x) {
+            const long long i = gidx << 2;
+            const int c = (int)((i / S) % C);
+            f((size_t)i, c, 4);
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)((i / S) % C);
+            f((size_t)i, c, 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, long long total, int C, int S,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int act, float* __restrict__ y) {
+    ncs_walk(total, C, S, [&](size_t i, int c, int cnt) {
+        const float a = gamma[c] * invstd[c];
+        const float b = beta[c] - mean[c] * a;
+        if (cnt == 4) {
+            float4 v = *reinterpret_cast<const float4*>(x + i);
+            v.x = act_apply(v.x * a + b, act);
+            v.y = act_apply(v.y * a + b, act);
+            v.z = act_apply(v.z * a + b, act);
+            v.w = act_apply(v.w * a + b, act);
+            *reinterpret_cast<float4*>(y + i) = v;
+        } else {
+            y[i] = act_apply(x[i] * a + b, act);
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ y, int N, int C, int S,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int act,
+                                                                float* __restrict__ red) {
+    const int c = blockIdx.y;
+    const float mu = mean[c], is = invstd[c];
+    float v[2] = {0.f, 0.f};   // dgamma, dbeta
+    channel_walk(N, C, S, c, [&](size_t off, int cnt) {
+        if (cnt == 4) {
+            float4 g = *reinterpret_cast<const float4*>(dy + off);
+            float4 xx = *reinterpret_cast<const float4*>(x + off);
+            float4 yy = *reinterpret_cast<const float4*>(y + off);
+            float d0 = g.x * act_grad_from_y(yy.x, act), d1 = g.y * act_grad_from_y(yy.y, act);
+            float d2 = g.z * act_grad_from_y(yy.z, act), d3 = g.w * act_grad_from_y(yy.w, act);
+            v[0] += d0 * (xx.x - mu) * is + d1 * (xx.y - mu) * is + d2 * (xx.z - mu) * is + d3 * (xx.w - mu) * is;
+            v[1] += (d0 + d1) + (d2 + d3);
+        } else {
+            float d = dy[off] * act_grad_from_y(y[off], act);
+            v[0] += d * (x[off] - mu) * is;
+            v[1] += d;
+        }
+    });
+    float* const dst[2] = {red + c, red + C + c};
+    block_atomic<2>(v, dst);
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ y, long long total, int C, int S,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, int act,
+                                                               const float* __restrict__ red, float inv_count, int train,
+                                                               float* __restrict__ dx) {
+    ncs_walk(total, C, S, [&](size_t i, int c, int cnt) {
+        const float mu = mean[c], is = invstd[c];
+        const float a = gamma[c] * is;
+        const float k1 = train ? red[C + c] * inv_count : 0.f;       // mean(dz)
+        const float k2 = train ? red[c] * inv_count : 0.f;           // mean(dz * xhat)
+        auto one = [&](float g, float xx, float yy) {
+            float dz = g * act_grad_from_y(yy, act);
+            return a * (dz - k1 - (xx - mu) * is * k2);
+        };
+        if (cnt == 4) {
+            float4 g = *reinterpret_cast<const float4*>(dy + i);
+            float4 xx = *reinterpret_cast<const float4*>(x + i);
+            float4 yy = *reinterpret_cast<const float4*>(y + i);
+            float4 o = make_float4(one(g.x, xx.x, yy.x), one(g.y, xx.y, yy.y), one(g.z, xx.z, yy.z), one(g.w, xx.w, yy.w));
+            *reinterpret_cast<float4*>(dx + i) = o;
+        } else {
+            dx[i] = one(dy[i], x[i], y[i]);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// gated activation  y = tanh(bn_f(yf)) * sigmoid(bn_g(yg)) * mask[n,c]
+// ------------------------------------------------------------------------------------------
+struct GateBN {
+    const float *mean_f, *invstd_f, *gamma_f, *beta_f;
+    const float *mean_g, *invstd_g, *gamma_g, *beta_g;
+};
+
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ yf, const float* __restrict__ yg,
+                                                       long long total, int C, int S, GateBN bn,
+                                                       const float* __restrict__ mask, float* __restrict__ y) {
+    ncs_walk(total, C, S, [&](size_t i, int c, int cnt) {
+        const float af = bn.gamma_f[c] * bn.invstd_f[c], bf = bn.beta_f[c] - bn.mean_f[c] * af;
+        const float ag = bn.gamma_g[c] * bn.invstd_g[c], bg = bn.beta_g[c] - bn.mean_g[c] * ag;
+        const float mk = mask ? mask[i / S] : 1.0f;
+        auto one = [&](float f, float g) { return tanhf(f * af + bf) * (1.0f / (1.0f + expf(-(g * ag + bg)))) * mk; };
+        if (cnt == 4) {
+            float4 f = *reinterpret_cast<const float4*>(yf + i);
+            float4 g = *reinterpret_cast<const float4*>(yg + i);
+            *reinterpret_cast<float4*>(y + i) = make_float4(one(f.x, g.x), one(f.y, g.y), one(f.z, g.z), one(f.w, g.w));
+        } else {
+            y[i] = one(yf[i], yg[i]);
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ yf,
+                                                              const float* __restrict__ yg, int N, int C, int S,
+                                                              GateBN bn, const float* __restrict__ mask,
+                                                              float* __restrict__ red) {
+    const int c = blockIdx.y;
+    const float muf = bn.mean_f[c], isf = bn.invstd_f[c], af = bn.gamma_f[c] * isf, bf = bn.beta_f[c] - muf * af;
+    const float mug = bn.mean_g[c], isg = bn.invstd_g[c], ag = bn.gamma_g[c] * isg, bg = bn.beta_g[c] - mug * ag;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};   // dgamma_f, dbeta_f, dgamma_g, dbeta_g
+    auto one = [&](size_t off) {
+        const float mk = mask ? mask[off / S] : 1.0f;
+        const float f = yf[off], g = yg[off];
+        const float t = tanhf(f * af + bf);
+        const float s = 1.0f / (1.0f + expf(-(g * ag + bg)));
+        const float d = dy[off] * mk;
+        const float dzf = d * s * (1.f - t * t);
+        const float dzg = d * t * s * (1.f - s);
+        v[0] += dzf * (f - muf) * isf;
+        v[1] += dzf;
+        v[2] += dzg * (g - mug) * isg;
+        v[3] += dzg;
+    };
+    channel_walk(N, C, S, c, [&](size_t off, int cnt) {
+        for (int k = 0; k < cnt; ++k) one(off + k);
+    });
+    float* const dst[4] = {red + c, red + C + c, red + 2 * C + c, red + 3 * C + c};
+    block_atomic<4>(v, dst);
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ yf,
+                                                             const float* __restrict__ yg, long long total, int C, int S,
+                                                             GateBN bn, const float* __restrict__ mask,
+                                                             const float* __restrict__ red, float inv_count, int train,
+                                                             float* __restrict__ dyf, float* __restrict__ dyg) {
+    ncs_walk(total, C, S, [&](size_t i, int c, int cnt) {
+        const float muf = bn.mean_f[c], isf = bn.invstd_f[c], af = bn.gamma_f[c] * isf, bf = bn.beta_f[c] - muf * af;
+        const float mug = bn.mean_g[c], isg = bn.invstd_g[c], ag = bn.gamma_g[c] * isg, bg = bn.beta_g[c] - mug * ag;
+        const float kf2 = train ? red[c] * inv_count : 0.f, kf1 = train ? red[C + c] * inv_count : 0.f;
+        const float kg2 = train ? red[2 * C + c] * inv_count : 0.f, kg1 = train ? red[3 * C + c] * inv_count : 0.f;
+        const float mk = mask ? mask[i / S] : 1.0f;
+        for (int k = 0; k < cnt; ++k) {
+            const size_t off = i + k;
+            const float f = yf[off], g = yg[off];
+            const float t = tanhf(f * af + bf);
+            const float s = 1.0f / (1.0f + expf(-(g * ag + bg)));
+            const float d = dy[off] * mk;
+            const float dzf = d * s * (1.f - t * t);
+            const float dzg = d * t * s * (1.f - s);
+            dyf[off] = af * (dzf - kf1 - (f - muf) * isf * kf2);
+            dyg[off] = ag * (dzg - kg1 - (g - mug) * isg * kg2);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// plain activations, add
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, long long n, int act,
+                                                      float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = act_apply(x[i], act);
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      long long n, int act, float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * act_grad_from_y(y[i], act);
+}
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  long long n, float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = a[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// max pooling, window == stride, floor mode.  x (NC, H, W) -> y (NC, H/ph, W/pw)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, long long NC, int H, int W,
+                                                          int ph, int pw, int OH, int OW, float* __restrict__ y,
+                                                          uint8_t* __restrict__ idx) {
+    const long long total = NC * OH * OW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ow = (int)(i % OW);
+        const long long t = i / OW;
+        const int oh = (int)(t % OH);
+        const long long nc = t / OH;
+        const float* base = x + ((size_t)nc * H + (size_t)oh * ph) * W + (size_t)ow * pw;
+        float best = base[0];
+        int bi = 0;
+        for (int a = 0; a < ph; ++a)
+            for (int b = 0; b < pw; ++b) {
+                const float v = base[(size_t)a * W + b];
+                if (v > best || v != v) {   // first maximum wins; NaN propagates (torch semantics)
+                    best = v;
+                    bi = a * pw + b;
+                }
+            }
+        y[i] = best;
+        if (idx) idx[i] = (uint8_t)bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          long long NC, int H, int W, int ph, int pw, int OH, int OW,
+                                                          float* __restrict__ dx) {
+    const long long total = NC * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const long long t = i / W;
+        const int h = (int)(t % H);
+        const long long nc = t / H;
+        const int oh = h / ph, ow = w / pw;
+        float v = 0.f;
+        if (oh < OH && ow < OW) {
+            const size_t o = ((size_t)nc * OH + oh) * OW + ow;
+            const int local = (h - oh * ph) * pw + (w - ow * pw);
+            if (idx[o] == local) v = dy[o];
+        }
+        dx[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox-4x32-10 dropout
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t counter, uint64_t key) {
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, long long n, float p, float scale,
+                                                      uint64_t seed, uint64_t offset, float* __restrict__ y) {
+    const long long groups = (n + 3) >> 2;
+    for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
+        const uint4 r = philox4x32_10(offset + (uint64_t)gi, seed);
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+        const long long i = gi << 2;
+        if (i + 3 < n) {
+            float4 v = *reinterpret_cast<const float4*>(x + i);
+            v.x = u01(rr[0]) >= p ? v.x * scale : 0.f;
+            v.y = u01(rr[1]) >= p ? v.y * scale : 0.f;
+            v.z = u01(rr[2]) >= p ? v.z * scale : 0.f;
+            v.w = u01(rr[3]) >= p ? v.w * scale : 0.f;
+            *reinterpret_cast<float4*>(y + i) = v;
+        } else {
+            for (int k = 0; k < 4 && i + k < n; ++k) y[i + k] = u01(rr[k]) >= p ? x[i + k] * scale : 0.f;
+        }
+    }
+}
+
+__global__ void dropout_mask_rows_kernel(long long rows, float p, float scale, uint64_t seed, uint64_t offset,
+                                         float* __restrict__ mask) {
+    const long long groups = (rows + 3) >> 2;
+    for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
+        const uint4 r = philox4x32_10(offset + (uint64_t)gi, seed);
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+        for (int k = 0; k < 4 && gi * 4 + k < rows; ++k) mask[gi * 4 + k] = u01(rr[k]) >= p ? scale : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// (N, C, T) <-> (N, T, C)
+// ------------------------------------------------------------------------------------------
+__global__ void transpose_kernel(const float* __restrict__ x, int R, int Cc, float* __restrict__ y) {
+    // per batch item: x (R, Cc) -> y (Cc, R)
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * R * Cc;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < R && c < Cc) tile[j][threadIdx.x] = x[base + (size_t)r * Cc + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < R && c < Cc) y[base + (size_t)c * R + r] = tile[threadIdx.x][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// loss = w_sed * mean BCE(sed, t_sed) + w_doa * mean MSE(doa, t_doa)     (train.py:186-204)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sed, const float* __restrict__ doa,
+                                                   const float* __restrict__ target, long long rows, int n_sed, int n_doa,
+                                                   float w_sed, float w_doa, float* __restrict__ loss,
+                                                   float* __restrict__ dsed, float* __restrict__ ddoa) {
+    const int ncol = n_sed + n_doa;
+    const long long total = rows * ncol;
+    const float inv_sed = 1.0f / (float)(rows * n_sed);
+    const float inv_doa = 1.0f / (float)(rows * n_doa);
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / ncol;
+        const int c = (int)(i - r * ncol);
+        const float t = target[i];
+        if (c < n_sed) {
+            const size_t o = (size_t)r * n_sed + c;
+            const float s = sed[o];
+            // torch.nn.BCELoss clamps the logs at -100
+            const float l1 = fmaxf(logf(s), -100.f), l0 = fmaxf(logf(1.f - s), -100.f);
+            acc += -(t * l1 + (1.f - t) * l0) * inv_sed * w_sed;
+            if (dsed) dsed[o] = w_sed * inv_sed * (s - t) / fmaxf(s * (1.f - s), 1e-12f);
+        } else {
+            const size_t o = (size_t)r * n_doa + (c - n_sed);
+            const float d = doa[o] - t;
+            acc += d * d * inv_doa * w_doa;
+            if (ddoa) ddoa[o] = w_doa * inv_doa * 2.f * d;
+        }
+    }
+    float v[1] = {acc};
+    float* const dst[1] = {loss};
+    block_atomic<1>(v, dst);
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam over a flat buffer (torch.optim.Adam, no amsgrad, L2 weight decay added to the grad)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                   float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float grad = g[i] * gscale;
+        const float pv = p[i];
+        if (wd != 0.f) grad += wd * pv;
+        const float mi = b1 * m[i] + (1.f - b1) * grad;
+        const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pv - (lr / bc1) * (mi / denom);
+    }
+}
+
+static inline unsigned grid_for(long long work_items, int per_block = 256, int cap = 8192) {
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+}  // namespace seld
+
+using namespace seld;
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int seld_channel_stats(const float* x, int32_t N, int32_t C, int32_t S, float* stats, void* stream) {
+    if (!x || !stats || N <= 0 || C <= 0 || S <= 0) return SELD_EINVAL;
+    const long long M = (long long)N * S;
+    dim3 grid((unsigned)((M + RED_CHUNK - 1) / RED_CHUNK), C);
+    hipLaunchKernelGGL(channel_stats_kernel, grid, dim3(256), 0, ST(stream), x, N, C, S, stats);
+    return check_launch();
+}
+
+extern "C" int seld_bn_finalize(const float* stats, int32_t C, int64_t count, float eps, float momentum, float* mean,
+                                float* invstd, float* running_mean, float* running_var, void* stream) {
+    if (!stats || !mean || !invstd || C <= 0 || count <= 0) return SELD_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), stats, C, (double)count, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    return check_launch();
+}
+
+extern "C" int seld_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
+                                  float* mean, float* invstd, void* stream) {
+    if (!running_mean || !running_var || !mean || !invstd || C <= 0) return SELD_EINVAL;
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), running_mean, running_var,
+                       C, eps, mean, invstd);
+    return check_launch();
+}
+
+extern "C" int seld_bn_act_fwd(const float* x, int32_t N, int32_t C, int32_t S, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, int32_t act, float* y, void* stream) {
+    if (!x || !y || !mean || !invstd || !gamma || !beta) return SELD_EINVAL;
+    const long long total = (long long)N * C * S;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total / 4 + 1)), dim3(256), 0, ST(stream), x, total, C, S, mean,
+                       invstd, gamma, beta, act, y);
+    return check_launch();
+}
+
+extern "C" int seld_bn_act_bwd_reduce(const float* dy, const float* x, const float* y, int32_t N, int32_t C, int32_t S,
+                                      const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                      int32_t act, float* red, void* stream) {
+    (void)gamma; (void)beta;
+    if (!dy || !x || !y || !red) return SELD_EINVAL;
+    const long long M = (long long)N * S;
+    dim3 grid((unsigned)((M + RED_CHUNK - 1) / RED_CHUNK), C);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, ST(stream), dy, x, y, N, C, S, mean, invstd, act, red);
+    return check_launch();
+}
+
+extern "C" int seld_bn_act_bwd_apply(const float* dy, const float* x, const float* y, int32_t N, int32_t C, int32_t S,
+                                     const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     int32_t act, const float* red, int32_t train, float* dx, void* stream) {
+    (void)beta;
+    if (!dy || !x || !y || !dx || (train && !red)) return SELD_EINVAL;
+    const long long total = (long long)N * C * S;
+    const float inv_count = 1.0f / (float)((long long)N * S);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(total / 4 + 1)), dim3(256), 0, ST(stream), dy, x, y, total,
+                       C, S, mean, invstd, gamma, act, red, inv_count, train, dx);
+    return check_launch();
+}
+
+static GateBN mk_gate(const float* mean_f, const float* invstd_f, const float* gamma_f, const float* beta_f,
+                      const float* mean_g, const float* invstd_g, const float* gamma_g, const float* beta_g) {
+    GateBN b{mean_f, invstd_f, gamma_f, beta_f, mean_g, invstd_g, gamma_g, beta_g};
+    return b;
+}
+
+extern "C" int seld_gate_fwd(const float* yf, const float* yg, int32_t N, int32_t C, int32_t S, const float* mean_f,
+                             const float* invstd_f, const float* gamma_f, const float* beta_f, const float* mean_g,
+                             const float* invstd_g, const float* gamma_g, const float* beta_g, const float* mask,
+                             float* y, void* stream) {
+    if (!yf || !yg || !y) return SELD_EINVAL;
+    const long long total = (long long)N * C * S;
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid_for(total / 4 + 1)), dim3(256), 0, ST(stream), yf, yg, total, C, S,
+                       mk_gate(mean_f, invstd_f, gamma_f, beta_f, mean_g, invstd_g, gamma_g, beta_g), mask, y);
+    return check_launch();
+}
+
+extern "C" int seld_gate_bwd_reduce(const float* dy, const float* yf, const float* yg, int32_t N, int32_t C, int32_t S,
+                                    const float* mean_f, const float* invstd_f, const float* gamma_f, const float* beta_f,
+                                    const float* mean_g, const float* invstd_g, const float* gamma_g, const float* beta_g,
+                                    const float* mask, float* red, void* stream) {
+    if (!dy || !yf || !yg || !red) return SELD_EINVAL;
+    const long long M = (long long)N * S;
+    dim3 grid((unsigned)((M + RED_CHUNK - 1) / RED_CHUNK), C);
+    hipLaunchKernelGGL(gate_bwd_reduce_kernel, grid, dim3(256), 0, ST(stream), dy, yf, yg, N, C, S,
+                       mk_gate(mean_f, invstd_f, gamma_f, beta_f, mean_g, invstd_g, gamma_g, beta_g), mask, red);
+    return check_launch();
+}
+
+extern "C" int seld_gate_bwd_apply(const float* dy, const float* yf, const float* yg, int32_t N, int32_t C, int32_t S,
+                                   const float* mean_f, const float* invstd_f, const float* gamma_f, const float* beta_f,
+                                   const float* mean_g, const float* invstd_g, const float* gamma_g, const float* beta_g,
+                                   const float* mask, const float* red, int32_t train, float* dyf, float* dyg,
+                                   void* stream) {
+    if (!dy || !yf || !yg || !dyf || !dyg || (train && !red)) return SELD_EINVAL;
+    const long long total = (long long)N * C * S;
+    const float inv_count = 1.0f / (float)((long long)N * S);
+    hipLaunchKernelGGL(gate_bwd_apply_kernel, dim3(grid_for(total / 4 + 1)), dim3(256), 0, ST(stream), dy, yf, yg, total,
+                       C, S, mk_gate(mean_f, invstd_f, gamma_f, beta_f, mean_g, invstd_g, gamma_g, beta_g), mask, red,
+                       inv_count, train, dyf, dyg);
+    return check_launch();
+}
+
+extern "C" int seld_act_fwd(const float* x, int64_t n, int32_t act, float* y, void* stream) {
+    if (!x || !y || n < 0) return SELD_EINVAL;
+    if (n == 0) return SELD_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, (long long)n, act, y);
+    return check_launch();
+}
+extern "C" int seld_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float* dx, void* stream) {
+    if (!dy || !y || !dx || n < 0) return SELD_EINVAL;
+    if (n == 0) return SELD_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), dy, y, (long long)n, act, dx);
+    return check_launch();
+}
+extern "C" int seld_add(const float* a, const float* b, int64_t n, float* y, void* stream) {
+    if (!a || !b || !y || n < 0) return SELD_EINVAL;
+    if (n == 0) return SELD_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), a, b, (long long)n, y);
+    return check_launch();
+}
+
+extern "C" int seld_maxpool_fwd(const float* x, int64_t NC, int32_t H, int32_t W, int32_t ph, int32_t pw, float* y,
+                                uint8_t* idx, void* stream) {
+    if (!x || !y || ph <= 0 || pw <= 0 || ph * pw > 255 || H < ph || W < pw) return SELD_EINVAL;
+    const int OH = H / ph, OW = W / pw;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(NC * OH * OW)), dim3(256), 0, ST(stream), x, (long long)NC, H, W,
+                       ph, pw, OH, OW, y, idx);
+    return check_launch();
+}
+extern "C" int seld_maxpool_bwd(const float* dy, const uint8_t* idx, int64_t NC, int32_t H, int32_t W, int32_t ph,
+                                int32_t pw, float* dx, void* stream) {
+    if (!dy || !idx || !dx || ph <= 0 || pw <= 0 || H < ph || W < pw) return SELD_EINVAL;
+    const int OH = H / ph, OW = W / pw;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(NC * H * W)), dim3(256), 0, ST(stream), dy, idx, (long long)NC, H,
+                       W, ph, pw, OH, OW, dx);
+    return check_launch();
+}
+
+extern "C" int seld_dropout_fwd(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, float* y,
+                                void* stream) {
+    if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return SELD_EINVAL;
+    if (n == 0) return SELD_OK;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, ST(stream), x, (long long)n, p,
+                       1.0f / (1.0f - p), seed, offset, y);
+    return check_launch();
+}
+extern "C" int seld_dropout_mask_rows(int64_t rows, float p, uint64_t seed, uint64_t offset, float* mask, void* stream) {
+    if (!mask || rows <= 0 || p < 0.f || p >= 1.f) return SELD_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_rows_kernel, dim3(grid_for((rows + 3) / 4)), dim3(256), 0, ST(stream), (long long)rows,
+                       p, 1.0f / (1.0f - p), seed, offset, mask);
+    return check_launch();
+}
+
+extern "C" int seld_transpose_nct_ntc(const float* x, int32_t N, int32_t C, int32_t T, float* y, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || T <= 0) return SELD_EINVAL;
+    dim3 grid((T + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, ST(stream), x, C, T, y);
+    return check_launch();
+}
+extern "C" int seld_transpose_ntc_nct(const float* x, int32_t N, int32_t T, int32_t C, float* y, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || T <= 0) return SELD_EINVAL;
+    dim3 grid((C + 31) / 32, (T + 31) / 32, N);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, ST(stream), x, T, C, y);
+    return check_launch();
+}
+
+extern "C" int seld_loss_fwd_bwd(const float* sed, const float* doa, const float* target, int64_t rows, int32_t n_sed,
+                                 int32_t n_doa, float w_sed, float w_doa, float* loss, float* dsed, float* ddoa,
+                                 void* stream) {
+    if (!sed || !doa || !target || !loss || rows <= 0 || n_sed <= 0 || n_doa <= 0) return SELD_EINVAL;
+    hipLaunchKernelGGL(loss_kernel, dim3(grid_for(rows * (n_sed + n_doa), 256, 1024)), dim3(256), 0, ST(stream), sed, doa,
+                       target, (long long)rows, n_sed, n_doa, w_sed, w_doa, loss, dsed, ddoa);
+    return check_launch();
+}
+
+extern "C" int seld_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                              void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return SELD_EINVAL;
+    if (n == 0) return SELD_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq,
+                       (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    return check_launch();
+}

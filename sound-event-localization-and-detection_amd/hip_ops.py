@@ -124,3 +124,477 @@ class HyperConvFn(torch.autograd.Function):
 
 def hyper_conv(x, ws, bias, stride, padding, dilation):
     return HyperConvFn.apply(x, bias, stride, padding, dilation, *ws)
+
+
+# ======================================================================================
+# conv with fused epilogue (bias / residual add) as an autograd op
+# ======================================================================================
+class HyperConvAddFn(torch.autograd.Function):
+    """y = W (x) x + addend  -- the `x + conv2_residual(y)` of model.py:132 and the running
+    skip-connection sum of model.py:210-212 ride in the conv epilogue (SELD_EPI_ADD)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, addend, stride, padding, dilation, *ws):
+        algebra = len(ws)
+        k = tuple(ws[0].shape[2:])
+        desc = make_conv_desc(tuple(x.shape), ws[0].shape[0] * algebra, algebra, k, stride, padding, dilation)
+        x = _req(x, "x")
+        y = conv_fwd(desc, x, ws, bias, epilogue=L.SELD_EPI_ADD, addend=addend)
+        ctx.desc = desc
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, *ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, *ws = ctx.saved_tensors
+        dy = _req(dy, "dy")
+        dx = conv_bwd_data(ctx.desc, dy, ws, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        dws, dbias = [None] * len(ws), None
+        if any(ctx.needs_input_grad[6:]) or (ctx.has_bias and ctx.needs_input_grad[1]):
+            dws, dbias = conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias)
+        return (dx, dbias, dy if ctx.needs_input_grad[2] else None, None, None, None, *dws)
+
+
+def hyper_conv_add(x, ws, bias, addend, stride, padding, dilation):
+    return HyperConvAddFn.apply(x, bias, addend, stride, padding, dilation, *ws)
+
+
+# ======================================================================================
+# BatchNorm + activation
+# ======================================================================================
+def _ncs(x):
+    N, C = x.shape[0], x.shape[1]
+    S = 1
+    for d in x.shape[2:]:
+        S *= d
+    return N, C, S
+
+
+def channel_stats(x):
+    N, C, S = _ncs(x)
+    stats = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    L.check(L.lib().seld_channel_stats(L.ptr(x), N, C, S, L.ptr(stats), L.current_stream()), "seld_channel_stats")
+    return stats
+
+
+def bn_prepare(x, running_mean, running_var, training, momentum, eps, stats=None):
+    """mean / invstd used by the normalisation; updates the running buffers in training mode."""
+    N, C, S = _ncs(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    if training:
+        if stats is None:
+            stats = channel_stats(x)
+        L.check(L.lib().seld_bn_finalize(L.ptr(stats), C, ctypes.c_int64(N * S), ctypes.c_float(eps),
+                                         ctypes.c_float(momentum), L.ptr(mean), L.ptr(invstd), L.ptr(running_mean),
+                                         L.ptr(running_var), L.current_stream()), "seld_bn_finalize")
+    else:
+        L.check(L.lib().seld_bn_eval_stats(L.ptr(running_mean), L.ptr(running_var), C, ctypes.c_float(eps),
+                                           L.ptr(mean), L.ptr(invstd), L.current_stream()), "seld_bn_eval_stats")
+    return mean, invstd
+
+
+class BnActFn(torch.autograd.Function):
+    """y = act(BatchNorm(x)); torch.nn.BatchNorm1d/2d + ReLU/Tanh of model.py:114-116, 279-280."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, stats):
+        x = _req(x, "x")
+        N, C, S = _ncs(x)
+        mean, invstd = bn_prepare(x, running_mean, running_var, training, momentum, eps, stats)
+        y = torch.empty_like(x)
+        L.check(L.lib().seld_bn_act_fwd(L.ptr(x), N, C, S, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta),
+                                        act, L.ptr(y), L.current_stream()), "seld_bn_act_fwd")
+        ctx.training, ctx.act = training, act
+        ctx.save_for_backward(x, y, mean, invstd, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma, beta = ctx.saved_tensors
+        dy = _req(dy, "dy")
+        N, C, S = _ncs(x)
+        red = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+        st = L.current_stream()
+        L.check(L.lib().seld_bn_act_bwd_reduce(L.ptr(dy), L.ptr(x), L.ptr(y), N, C, S, L.ptr(mean), L.ptr(invstd),
+                                               L.ptr(gamma), L.ptr(beta), ctx.act, L.ptr(red), st),
+                "seld_bn_act_bwd_reduce")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.check(L.lib().seld_bn_act_bwd_apply(L.ptr(dy), L.ptr(x), L.ptr(y), N, C, S, L.ptr(mean), L.ptr(invstd),
+                                                  L.ptr(gamma), L.ptr(beta), ctx.act, L.ptr(red), int(ctx.training),
+                                                  L.ptr(dx), st), "seld_bn_act_bwd_apply")
+        return dx, red[:C], red[C:], None, None, None, None, None, None, None
+
+
+def bn_act(x, bn, act, stats=None):
+    """`bn` is a torch.nn.BatchNorm*-shaped module (weight, bias, running_mean, running_var, ...)."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
+                         bn.momentum if bn.momentum is not None else 0.1, bn.eps, act, stats)
+
+
+class GateFn(torch.autograd.Function):
+    """y = tanh(BN_f(yf)) * sigmoid(BN_g(yg)) * channel_mask  (model.py:121-128)."""
+
+    @staticmethod
+    def forward(ctx, yf, yg, gf, bf, rmf, rvf, gg, bg, rmg, rvg, training, momentum, eps, mask):
+        yf, yg = _req(yf, "yf"), _req(yg, "yg")
+        N, C, S = _ncs(yf)
+        mf, isf = bn_prepare(yf, rmf, rvf, training, momentum, eps)
+        mg, isg = bn_prepare(yg, rmg, rvg, training, momentum, eps)
+        y = torch.empty_like(yf)
+        L.check(L.lib().seld_gate_fwd(L.ptr(yf), L.ptr(yg), N, C, S, L.ptr(mf), L.ptr(isf), L.ptr(gf), L.ptr(bf),
+                                      L.ptr(mg), L.ptr(isg), L.ptr(gg), L.ptr(bg), L.ptr(mask), L.ptr(y),
+                                      L.current_stream()), "seld_gate_fwd")
+        ctx.training = training
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(yf, yg, mf, isf, gf, bf, mg, isg, gg, bg, *([mask] if mask is not None else []))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        yf, yg, mf, isf, gf, bf, mg, isg, gg, bg, *rest = ctx.saved_tensors
+        mask = rest[0] if ctx.has_mask else None
+        dy = _req(dy, "dy")
+        N, C, S = _ncs(yf)
+        red = torch.zeros(4 * C, device=yf.device, dtype=torch.float32)
+        st = L.current_stream()
+        args = (L.ptr(dy), L.ptr(yf), L.ptr(yg), N, C, S, L.ptr(mf), L.ptr(isf), L.ptr(gf), L.ptr(bf),
+                L.ptr(mg), L.ptr(isg), L.ptr(gg), L.ptr(bg), L.ptr(mask))
+        L.check(L.lib().seld_gate_bwd_reduce(*args, L.ptr(red), st), "seld_gate_bwd_reduce")
+        dyf, dyg = torch.empty_like(yf), torch.empty_like(yg)
+        L.check(L.lib().seld_gate_bwd_apply(*args, L.ptr(red), int(ctx.training), L.ptr(dyf), L.ptr(dyg), st),
+                "seld_gate_bwd_apply")
+        return (dyf, dyg, red[:C], red[C:2 * C], None, None, red[2 * C:3 * C], red[3 * C:], None, None,
+                None, None, None, None)
+
+
+def gate(yf, yg, bn_f, bn_g, mask=None):
+    for bn in (bn_f, bn_g):
+        if bn.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+    return GateFn.apply(yf, yg, bn_f.weight, bn_f.bias, bn_f.running_mean, bn_f.running_var,
+                        bn_g.weight, bn_g.bias, bn_g.running_mean, bn_g.running_var, bn_f.training,
+                        bn_f.momentum if bn_f.momentum is not None else 0.1, bn_f.eps, mask)
+
+
+# ======================================================================================
+# activations, pooling, dropout, transposes
+# ======================================================================================
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = _req(x, "x")
+        y = torch.empty_like(x)
+        L.check(L.lib().seld_act_fwd(L.ptr(x), ctypes.c_int64(x.numel()), act, L.ptr(y), L.current_stream()), "seld_act_fwd")
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _req(dy, "dy")
+        dx = torch.empty_like(y)
+        L.check(L.lib().seld_act_bwd(L.ptr(dy), L.ptr(y), ctypes.c_int64(y.numel()), ctx.act, L.ptr(dx),
+                                     L.current_stream()), "seld_act_bwd")
+        return dx, None
+
+
+def act(x, kind):
+    return ActFn.apply(x, kind)
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """torch.nn.MaxPool1d / MaxPool2d with stride == window (model.py:178,192,202,281)."""
+
+    @staticmethod
+    def forward(ctx, x, ph, pw):
+        x = _req(x, "x")
+        if x.dim() == 3:
+            N, C, H, W = x.shape[0], x.shape[1], 1, x.shape[2]
+            oshape = (N, C, W // pw)
+        else:
+            N, C, H, W = x.shape
+            oshape = (N, C, H // ph, W // pw)
+        y = torch.empty(oshape, device=x.device, dtype=torch.float32)
+        idx = torch.empty(oshape, device=x.device, dtype=torch.uint8)
+        L.check(L.lib().seld_maxpool_fwd(L.ptr(x), ctypes.c_int64(N * C), H, W, ph, pw, L.ptr(y), L.ptr(idx),
+                                         L.current_stream()), "seld_maxpool_fwd")
+        ctx.geom = (N * C, H, W, ph, pw, tuple(x.shape))
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        NC, H, W, ph, pw, xshape = ctx.geom
+        dy = _req(dy, "dy")
+        dx = torch.empty(xshape, device=dy.device, dtype=torch.float32)
+        L.check(L.lib().seld_maxpool_bwd(L.ptr(dy), L.ptr(idx), ctypes.c_int64(NC), H, W, ph, pw, L.ptr(dx),
+                                         L.current_stream()), "seld_maxpool_bwd")
+        return dx, None, None
+
+
+def maxpool(x, ph, pw):
+    if ph == 1 and pw == 1:
+        return x
+    return MaxPoolFn.apply(x, int(ph), int(pw))
+
+
+class _Philox:
+    """Counter-based RNG bookkeeping for the dropout kernels (seed from torch's generator so
+    torch.manual_seed controls it; the offset advances by the number of 128-bit draws)."""
+
+    def __init__(self):
+        self.offset = 0
+
+    def draw(self, n_groups):
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        off = self.offset
+        self.offset += int(n_groups)
+        return seed, off
+
+
+philox = _Philox()
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _req(x, "x")
+        n = x.numel()
+        seed, off = philox.draw((n + 3) // 4)
+        y = torch.empty_like(x)
+        L.check(L.lib().seld_dropout_fwd(L.ptr(x), ctypes.c_int64(n), ctypes.c_float(p), ctypes.c_uint64(seed),
+                                         ctypes.c_uint64(off), L.ptr(y), L.current_stream()), "seld_dropout_fwd")
+        ctx.rng = (p, seed, off)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, off = ctx.rng
+        dy = _req(dy, "dy")
+        dx = torch.empty_like(dy)
+        L.check(L.lib().seld_dropout_fwd(L.ptr(dy), ctypes.c_int64(dy.numel()), ctypes.c_float(p),
+                                         ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(dx), L.current_stream()),
+                "seld_dropout_fwd")
+        return dx, None
+
+
+def dropout(x, p, training):
+    if not training or p == 0.0:
+        return x
+    return DropoutFn.apply(x, float(p))
+
+
+def channel_dropout_mask(N, C, p, device):
+    """Dropout1d decision per (n, c) row, already scaled by 1/(1-p) (model.py:96-97,127-128)."""
+    rows = N * C
+    seed, off = philox.draw((rows + 3) // 4)
+    mask = torch.empty(rows, device=device, dtype=torch.float32)
+    L.check(L.lib().seld_dropout_mask_rows(ctypes.c_int64(rows), ctypes.c_float(p), ctypes.c_uint64(seed),
+                                           ctypes.c_uint64(off), L.ptr(mask), L.current_stream()),
+            "seld_dropout_mask_rows")
+    return mask
+
+
+class RowScaleFn(torch.autograd.Function):
+    """y[n, c, :] = x[n, c, :] * mask[n*C + c]  (stand-alone Dropout1d; inside ResBlock the mask rides in the gate kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return _rowscale(x, mask)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return _rowscale(_req(dy, "dy"), mask), None
+
+
+def _rowscale(x, mask):
+    # gate kernel with neutral BN constants would be overkill; use bn_act_fwd with gamma = mask per (n,c):
+    # treat (N, C, S) as (1, N*C, S) with mean 0, invstd 1, gamma = mask, beta = 0
+    x = _req(x, "x")
+    N, C, S = _ncs(x)
+    zeros = torch.zeros(N * C, device=x.device, dtype=torch.float32)
+    ones = torch.ones(N * C, device=x.device, dtype=torch.float32)
+    y = torch.empty_like(x)
+    L.check(L.lib().seld_bn_act_fwd(L.ptr(x), 1, N * C, S, L.ptr(zeros), L.ptr(ones), L.ptr(mask), L.ptr(zeros),
+                                    L.SELD_ACT_NONE, L.ptr(y), L.current_stream()), "seld_bn_act_fwd")
+    return y
+
+
+class TransposeFn(torch.autograd.Function):
+    """(N, A, B) -> (N, B, A) contiguous."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "x")
+        N, A, B = x.shape
+        y = torch.empty((N, B, A), device=x.device, dtype=torch.float32)
+        L.check(L.lib().seld_transpose_nct_ntc(L.ptr(x), N, A, B, L.ptr(y), L.current_stream()), "seld_transpose")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return TransposeFn.apply(dy)
+
+
+def transpose12(x):
+    return TransposeFn.apply(x)
+
+
+# ======================================================================================
+# linear layers
+# ======================================================================================
+class HyperLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, kind, *ws):
+        x2 = _req(x.reshape(-1, x.shape[-1]), "x")
+        rows, in_f = x2.shape
+        if kind == L.SELD_LIN_REAL:
+            out_f = ws[0].shape[0]
+        else:
+            out_f = ws[0].shape[1] * kind
+        ws = [_req(w, "w") for w in ws]
+        y = torch.empty((rows, out_f), device=x.device, dtype=torch.float32)
+        L.check(L.lib().seld_hc_linear_fwd(kind, rows, in_f, out_f, L.ptr(x2), L.ptr_array8(ws), L.ptr(_req(bias, "bias")),
+                                           L.ptr(y), L.current_stream()), "seld_hc_linear_fwd")
+        ctx.meta = (kind, rows, in_f, out_f, tuple(x.shape), bias is not None)
+        ctx.save_for_backward(x2, *ws)
+        return y.reshape(*x.shape[:-1], out_f)
+
+    @staticmethod
+    def backward(ctx, dy):
+        kind, rows, in_f, out_f, xshape, has_bias = ctx.meta
+        x2, *ws = ctx.saved_tensors
+        dy2 = _req(dy.reshape(rows, out_f), "dy")
+        dev = dy2.device
+        dx = torch.empty((rows, in_f), device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        need_w = any(ctx.needs_input_grad[3:])
+        dws = [torch.empty_like(w) for w in ws] if need_w else None
+        dbias = torch.empty(out_f, device=dev, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[1]) else None
+        nbytes = L.lib().seld_hc_linear_bwd_workspace(kind, in_f, out_f)
+        wsb = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+        L.check(L.lib().seld_hc_linear_bwd(kind, rows, in_f, out_f, L.ptr(x2), L.ptr(dy2), L.ptr_array8(ws), L.ptr(dx),
+                                           L.ptr_array8(dws) if dws is not None else None, L.ptr(dbias), L.ptr(wsb),
+                                           ctypes.c_size_t(nbytes), L.current_stream()), "seld_hc_linear_bwd")
+        return (dx.reshape(xshape) if dx is not None else None, dbias, None, *(dws if dws is not None else [None] * len(ws)))
+
+
+def hyper_linear(x, ws, bias, kind):
+    return HyperLinearFn.apply(x, bias, kind, *ws)
+
+
+# ======================================================================================
+# attention core, loss, Adam, STFT
+# ======================================================================================
+class MhaCoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v on (N, E, T) tensors (model.py:39-48)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        q, k, v = _req(q, "q"), _req(k, "k"), _req(v, "v")
+        N, E, T = q.shape
+        hd = E // heads
+        out = torch.empty_like(q)
+        lse = torch.empty((N, heads, T), device=q.device, dtype=torch.float32)
+        L.check(L.lib().seld_mha_fwd(L.ptr(q), L.ptr(k), L.ptr(v), N, T, heads, hd, L.ptr(out), L.ptr(lse),
+                                     L.current_stream()), "seld_mha_fwd")
+        ctx.geom = (N, T, heads, hd)
+        ctx.save_for_backward(q, k, v, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        N, T, H, hd = ctx.geom
+        dout = _req(dout, "dout")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        lib = L.lib()
+        lib.seld_mha_bwd_workspace.restype = ctypes.c_size_t
+        nbytes = lib.seld_mha_bwd_workspace(N, T, H)
+        wsb = torch.empty((nbytes + 3) // 4, device=q.device, dtype=torch.float32)
+        L.check(lib.seld_mha_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(dout), L.ptr(lse), N, T, H, hd,
+                                 L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(wsb), ctypes.c_size_t(nbytes),
+                                 L.current_stream()), "seld_mha_bwd")
+        return dq, dk, dv, None
+
+
+def mha_core(q, k, v, heads):
+    return MhaCoreFn.apply(q, k, v, heads)
+
+
+class SeldLossFn(torch.autograd.Function):
+    """BCELoss(sed, t_sed) * w_sed + MSELoss(doa, t_doa) * w_doa  (train.py:186-204)."""
+
+    @staticmethod
+    def forward(ctx, sed, doa, target, w_sed, w_doa):
+        sed2 = _req(sed.reshape(-1, sed.shape[-1]), "sed")
+        doa2 = _req(doa.reshape(-1, doa.shape[-1]), "doa")
+        tgt = _req(target.reshape(-1, target.shape[-1]), "target")
+        rows, n_sed = sed2.shape
+        n_doa = doa2.shape[1]
+        loss = torch.zeros(1, device=sed.device, dtype=torch.float32)
+        dsed, ddoa = torch.empty_like(sed2), torch.empty_like(doa2)
+        L.check(L.lib().seld_loss_fwd_bwd(L.ptr(sed2), L.ptr(doa2), L.ptr(tgt), ctypes.c_int64(rows), n_sed, n_doa,
+                                          ctypes.c_float(w_sed), ctypes.c_float(w_doa), L.ptr(loss), L.ptr(dsed),
+                                          L.ptr(ddoa), L.current_stream()), "seld_loss_fwd_bwd")
+        ctx.shapes = (tuple(sed.shape), tuple(doa.shape))
+        ctx.save_for_backward(dsed, ddoa)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dsed, ddoa = ctx.saved_tensors
+        s1, s2 = ctx.shapes
+        return (dsed * g).reshape(s1), (ddoa * g).reshape(s2), None, None, None
+
+
+def seld_loss(sed, doa, target, w_sed=1.0, w_doa=5.0):
+    return SeldLossFn.apply(sed, doa, target, float(w_sed), float(w_doa))
+
+
+def adam_flat_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8,
+                   weight_decay=0.0, grad_scale=1.0):
+    L.check(L.lib().seld_adam_flat(L.ptr(param), L.ptr(grad), L.ptr(exp_avg), L.ptr(exp_avg_sq),
+                                   ctypes.c_int64(param.numel()), ctypes.c_float(lr), ctypes.c_float(beta1),
+                                   ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(weight_decay), int(step),
+                                   ctypes.c_float(grad_scale), L.current_stream()), "seld_adam_flat")
+
+
+def stft_magphase(x, nperseg=512, noverlap=128, output_phase=True):
+    """x: (C, L) float32 device tensor -> (C or 2C, nperseg/2, frames) (utility_functions.py:129-155)."""
+    x = _req(x, "x")
+    C, Ln = x.shape
+    frames = L.lib().seld_stft_frames(Ln, nperseg, noverlap)
+    if frames <= 0:
+        raise L.SeldHipError("seld_stft_frames: invalid segment parameters")
+    out = torch.empty(((2 if output_phase else 1) * C, nperseg // 2, frames), device=x.device, dtype=torch.float32)
+    L.check(L.lib().seld_stft_magphase(L.ptr(x), C, Ln, nperseg, noverlap, int(bool(output_phase)), L.ptr(out),
+                                       L.current_stream()), "seld_stft_magphase")
+    return out
+
+
+_identity_cache = {}
+
+
+def gate_plain(yf, yg, mask=None):
+    """tanh(yf) * sigmoid(yg) * mask for batch_norm='noBN' models: the gate kernel with identity
+    normalisation constants (mean 0, invstd 1, gamma 1, beta 0) and eval-mode backward."""
+    C = yf.shape[1]
+    key = (yf.device, C)
+    if key not in _identity_cache:
+        _identity_cache[key] = (torch.zeros(C, device=yf.device), torch.ones(C, device=yf.device))
+    zero, one = _identity_cache[key]
+
+    class _Id:
+        weight, bias, running_mean, running_var = one, zero, zero, one
+        training, momentum, eps, num_batches_tracked = False, 0.1, 0.0, None
+    return GateFn.apply(yf, yg, one, zero, zero, one, one, zero, zero, one, False, 0.1, 0.0, mask)

@@ -1,0 +1,346 @@
+"""Training harness with the CLI of the reference's train.py (`python train.py --TextArgs=config/X.txt`,
+same flag names and defaults, train.py:719-818) and its step semantics (train.py:186-204, 498-508, 538-571):
+
+    zero_grad -> forward -> BCELoss(sed) * w_sed + MSELoss(doa) * w_doa -> backward -> Adam(lr 1e-4)
+
+on the gfx950 kernels: the loss is one fused kernel, Adam is ONE launch over a flat parameter buffer,
+and under torch.distributed (one process per GPU, RCCL) the gradient exchange is ONE all-reduce of the
+flat gradient buffer (the reference is single-device).
+
+The reference's own `main()` cannot run on a current stack (np.Inf, StepLR(verbose=), wandb, ...);
+this file restates its behaviour rather than its text.
+"""
+import argparse
+import ast
+import os
+import pickle
+import shutil
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip_ops as H
+from .model import SELD_Model
+
+
+# ------------------------------------------------------------------------------------------
+# loss / optimiser
+# ------------------------------------------------------------------------------------------
+def seld_loss_fn(sed, doa, target, n_sed, sed_weight=1.0, doa_weight=5.0):
+    """BCE(sed, target[..., :n_sed]) * sed_weight + MSE(doa, target[..., n_sed:]) * doa_weight, both means."""
+    assert target.shape[-1] == sed.shape[-1] + doa.shape[-1] and sed.shape[-1] == n_sed
+    return H.seld_loss(sed, doa, target, sed_weight, doa_weight)
+
+
+class BCELoss(nn.Module):
+    """Marker modules so that `seld_loss(x, target, model, criterion_sed, criterion_doa)` keeps the reference's
+    signature; the two criteria are evaluated together by one fused kernel."""
+
+
+class MSELoss(nn.Module):
+    pass
+
+
+def seld_loss(x, target, model, criterion_sed, criterion_doa, args=None):
+    """train.py:186-204.  `args` carries output_classes / class_overlaps / loss weights (the reference reads a
+    module-level global)."""
+    a = args if args is not None else globals().get("args")
+    n_sed = int(a.output_classes * a.class_overlaps)
+    sed, doa = model(x)
+    if isinstance(criterion_sed, BCELoss) and isinstance(criterion_doa, MSELoss):
+        return seld_loss_fn(sed, doa, target, n_sed, a.sed_loss_weight, a.doa_loss_weight)
+    t_sed, t_doa = target[:, :, :n_sed], target[:, :, n_sed:]
+    return criterion_sed(torch.flatten(sed, 1), torch.flatten(t_sed, 1)) * a.sed_loss_weight + \
+        criterion_doa(torch.flatten(doa, 1), torch.flatten(t_doa, 1)) * a.doa_loss_weight
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (train.py:502) with every parameter, gradient and moment living in one
+    flat fp32 buffer each: `step()` is a single kernel launch and a data-parallel gradient exchange is a
+    single all-reduce of `flat_grad` (see dp.py).  Parameters that never receive a gradient (SURVEY App. B:
+    batch_gate1.*, the last block's conv2_residual) keep a zero gradient, which leaves them unchanged, as
+    torch.optim.Adam does by skipping them."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdam: no parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat_param = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[off:off + n].view(p.shape)
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+                off += n
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=self.params)]
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        off = 0
+        for p in self.params:           # re-attach views if something replaced .grad
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+            off += n
+
+    def step(self, grad_scale=1.0):
+        g = self.param_groups[0]
+        self.step_count += 1
+        H.adam_flat_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"],
+                         g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], grad_scale)
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,
+                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0].update(sd["param_groups"][0])
+
+
+class StepLR:
+    """torch.optim.lr_scheduler.StepLR(step_size, gamma) for FlatAdam (train.py:505-508, 570-571)."""
+
+    def __init__(self, optimizer, step_size, gamma=0.1):
+        self.opt, self.step_size, self.gamma = optimizer, step_size, gamma
+        self.base_lr = optimizer.param_groups[0]["lr"]
+        self.last_epoch = 0
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.param_groups[0]["lr"] = self.base_lr * self.gamma ** (self.last_epoch // self.step_size)
+
+    def state_dict(self):
+        return dict(last_epoch=self.last_epoch, base_lr=self.base_lr, step_size=self.step_size, gamma=self.gamma)
+
+    def load_state_dict(self, sd):
+        self.__dict__.update({k: sd[k] for k in ("last_epoch", "base_lr", "step_size", "gamma")})
+
+
+# ------------------------------------------------------------------------------------------
+# configuration (train.py:718-838, utility_functions.py:77-91)
+# ------------------------------------------------------------------------------------------
+def readFile(path):
+    """Tokenise a flag file: split on '=' and newlines, 'True' -> '1', 'False' -> 0, drop '#' tokens."""
+    with open(path, 'r') as f:
+        toks = f.read().replace('=', '+').replace('\n', '+').split('+')
+    out = []
+    for t in toks:
+        if t == 'True':
+            out.append('1')
+        elif t == 'False':
+            out.append(0)
+        elif t != '' and '#' not in t:
+            out.append(t)
+    return out
+
+
+_FLAGS = [
+    ('results_path', str, 'RESULTS/Task2'), ('checkpoint_dir', str, 'RESULTS/Task2'), ('load_model', str, None),
+    ('training_predictors_path', str, '/var/datasets/L3DAS21/processed/task2_predictors_train.pkl'),
+    ('training_target_path', str, '/var/datasets/L3DAS21/processed/task2_target_train.pkl'),
+    ('validation_predictors_path', str, '/var/datasets/L3DAS21/processed/task2_predictors_validation.pkl'),
+    ('validation_target_path', str, '/var/datasets/L3DAS21/processed/task2_target_validation.pkl'),
+    ('test_predictors_path', str, '/var/datasets/L3DAS21/processed/task2_predictors_test.pkl'),
+    ('test_target_path', str, '/var/datasets/L3DAS21/processed/task2_target_test.pkl'),
+    ('gpu_id', int, 0), ('use_cuda', str, 'True'), ('early_stopping', str, 'True'), ('fixed_seed', str, 'True'),
+    ('lr', float, 0.0001), ('batch_size', int, 1), ('sr', int, 32000), ('patience', int, 250),
+    ('architecture', str, 'DualQSELD-TCN'), ('input_channels', int, 4), ('n_mics', int, 1), ('phase', str, 'False'),
+    ('class_overlaps', int, 3), ('time_dim', int, 4800), ('freq_dim', int, 256), ('output_classes', int, 14),
+    ('pool_size', str, '[[8,2],[8,2],[2,2],[1,1]]'), ('cnn_filters', str, '[64,64,64]'), ('pool_time', str, 'True'),
+    ('dropout_perc', float, 0.3), ('D', str, '[10]'), ('G', int, 128), ('U', int, 128), ('V', str, '[128,128]'),
+    ('spatial_dropout_rate', float, 0.5), ('batch_norm', str, 'BN'), ('dilation_mode', str, 'fibonacci'),
+    ('model_extra_name', str, ''), ('test_mode', str, 'test_best'), ('use_lr_scheduler', str, 'True'),
+    ('lr_scheduler_step_size', int, 150), ('lr_scheduler_gamma', float, 0.5), ('min_lr', float, 0.000005),
+    ('dataset_normalization', str, 'True'), ('kernel_size_cnn_blocks', int, 3), ('kernel_size_dilated_conv', int, 3),
+    ('use_tcn', str, 'True'), ('use_bias_conv', str, 'True'), ('use_bias_linear', str, 'True'), ('verbose', str, 'False'),
+    ('sed_loss_weight', float, 1.), ('doa_loss_weight', float, 5.), ('domain_classifier', str, 'same'),
+    ('domain', str, 'DQ'), ('fc_activations', str, 'Linear'), ('fc_dropout', str, 'Last'), ('fc_layers', str, '[128]'),
+    ('V_kernel_size', int, 3), ('use_time_distributed', str, 'False'), ('parallel_ConvTC_block', str, 'False'),
+    ('max_loc_value', float, 2.), ('num_frames', int, 600), ('spatial_threshold', float, 2.),
+    ('checkpoint_step', int, 100), ('test_step', int, 10), ('min_n_epochs', int, 1000),
+    ('Dcase21_metrics_DOA_threshold', int, 20), ('parallel_magphase', str, 'False'),
+    ('TextArgs', str, 'config/Test.txt'),
+]
+_EVAL = ('use_cuda', 'early_stopping', 'fixed_seed', 'pool_size', 'cnn_filters', 'verbose', 'D', 'V', 'use_lr_scheduler',
+         'phase', 'use_tcn', 'use_bias_conv', 'use_bias_linear', 'fc_layers', 'parallel_magphase')
+# extensions of this implementation (not in the reference): synthetic data so the step can run without L3DAS21
+_EXTRA = [('synthetic', int, 0), ('max_steps', int, 0), ('epochs', int, 0)]
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    for name, typ, default in _FLAGS + _EXTRA:
+        p.add_argument('--' + name, type=typ, default=default)
+    return p
+
+
+def parse_args(argv=None):
+    """Two-pass parse like train.py:819-820: argv selects --TextArgs, the file supplies the flags.  Flags the
+    reference's parser would reject (e.g. --phm_n in the shipped Q config) are reported, not fatal."""
+    parser = build_parser()
+    first, _ = parser.parse_known_args(argv)
+    tokens = [str(t) for t in readFile(first.TextArgs)] if os.path.isfile(first.TextArgs) else []
+    args, unknown = parser.parse_known_args(tokens + list(argv or []))
+    if unknown:
+        print("ignoring flags unknown to the reference's parser:", unknown, file=sys.stderr)
+    for k in _EVAL:
+        v = getattr(args, k)
+        if isinstance(v, str):
+            setattr(args, k, ast.literal_eval(v))
+    return args
+
+
+def model_from_args(args):
+    """train.py:448-465."""
+    return SELD_Model(time_dim=args.time_dim, freq_dim=args.freq_dim, input_channels=args.input_channels,
+                      output_classes=args.output_classes, domain=args.domain, domain_classifier=args.domain_classifier,
+                      cnn_filters=args.cnn_filters, kernel_size_cnn_blocks=args.kernel_size_cnn_blocks,
+                      pool_size=args.pool_size, pool_time=args.pool_time, D=args.D, dilation_mode=args.dilation_mode,
+                      G=args.G, U=args.U, kernel_size_dilated_conv=args.kernel_size_dilated_conv,
+                      spatial_dropout_rate=args.spatial_dropout_rate, V=args.V, V_kernel_size=args.V_kernel_size,
+                      fc_layers=args.fc_layers, fc_activations=args.fc_activations, fc_dropout=args.fc_dropout,
+                      dropout_perc=args.dropout_perc, class_overlaps=args.class_overlaps, use_bias_conv=args.use_bias_conv,
+                      use_bias_linear=args.use_bias_linear, batch_norm=args.batch_norm,
+                      parallel_ConvTC_block=args.parallel_ConvTC_block, parallel_magphase=args.parallel_magphase,
+                      extra_name=args.model_extra_name, verbose=args.verbose)
+
+
+# ------------------------------------------------------------------------------------------
+# checkpoints (train.py:26-81): same dictionary keys, `module.` prefixes stripped on load
+# ------------------------------------------------------------------------------------------
+def save_model(model, optimizer, state, path, scheduler=None):
+    sd = model.module.state_dict() if hasattr(model, "module") else model.state_dict()
+    ck = {'model_state_dict': sd, 'optimizer_state_dict': optimizer.state_dict() if optimizer is not None else None,
+          'state': state,
+          'random_states': (np.random.get_state(), torch.get_rng_state(),
+                            torch.cuda.get_rng_state() if torch.cuda.is_available() else None)}
+    if scheduler is not None:
+        ck['scheduler_state_dict'] = scheduler.state_dict()
+    torch.save(ck, path)
+
+
+def load_model(model, optimizer, path, cuda, device, scheduler=None):
+    ck = torch.load(path, map_location=device, weights_only=False)
+    sd = {(k[7:] if k.startswith('module.') else k): v for k, v in ck['model_state_dict'].items()}
+    target = model.module if hasattr(model, "module") else model
+    target.load_state_dict(sd)
+    if optimizer is not None and ck.get('optimizer_state_dict') is not None and 'exp_avg' in ck['optimizer_state_dict']:
+        optimizer.load_state_dict(ck['optimizer_state_dict'])
+    if scheduler is not None and 'scheduler_state_dict' in ck:
+        scheduler.load_state_dict(ck['scheduler_state_dict'])
+    return ck.get('state', {})
+
+
+# ------------------------------------------------------------------------------------------
+# data
+# ------------------------------------------------------------------------------------------
+def synthetic_batch(batch, channels, freq, time, n_out, seed, device):
+    """x ~ N(0,1); target = [Bernoulli(0.1) (B, T/8, n_sed) | U(-1,1) (B, T/8, 3 n_sed)]."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, channels, freq, time, generator=g)
+    sed = (torch.rand(batch, time // 8, n_out, generator=g) < 0.1).float()
+    doa = torch.rand(batch, time // 8, 3 * n_out, generator=g) * 2 - 1
+    return x.to(device), torch.cat((sed, doa), 2).to(device)
+
+
+def load_pickled(pred_path, target_path):
+    with open(pred_path, 'rb') as f:
+        x = np.array(pickle.load(f))
+    with open(target_path, 'rb') as f:
+        y = np.array(pickle.load(f))
+    return torch.tensor(x).float(), torch.tensor(y).float()
+
+
+def evaluate(model, device, criterion_sed, criterion_doa, loader, args):
+    """Mean loss over a loader, no grad (train.py:168-183)."""
+    model.eval()
+    total, n = 0.0, 0
+    with torch.no_grad():
+        for x, target in loader:
+            loss = seld_loss(x.to(device), target.to(device), model, criterion_sed, criterion_doa, args)
+            n += 1
+            total += (loss.item() - total) / n
+    return total
+
+
+def main(args):
+    device = torch.device('cuda:' + str(args.gpu_id)) if args.use_cuda else None
+    if device is None or not torch.cuda.is_available():
+        raise RuntimeError("this implementation has no CPU path: a HIP device is required")
+    if args.fixed_seed:
+        np.random.seed(1)
+        torch.manual_seed(1)
+    model = model_from_args(args).to(device)
+    print('Total paramters: ' + str(sum(int(np.prod(p.size())) for p in model.parameters())))
+    criterion_sed, criterion_doa = BCELoss(), MSELoss()
+    optimizer = FlatAdam(model.parameters(), lr=args.lr)
+    scheduler = StepLR(optimizer, args.lr_scheduler_step_size, args.lr_scheduler_gamma) if args.use_lr_scheduler else None
+    n_out = int(args.output_classes * args.class_overlaps)
+
+    if args.synthetic:
+        data = [synthetic_batch(args.batch_size, args.input_channels, args.freq_dim, args.time_dim, n_out, 1234 + i, device)
+                for i in range(args.synthetic)]
+        tr_data, val_data = data, data[:1]
+    else:
+        xs, ys = load_pickled(args.training_predictors_path, args.training_target_path)
+        xv, yv = load_pickled(args.validation_predictors_path, args.validation_target_path)
+        tr_data = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xs, ys), args.batch_size, shuffle=True,
+                                              pin_memory=True)
+        val_data = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xv, yv), args.batch_size, shuffle=False,
+                                               pin_memory=True)
+
+    model_dir = os.path.join(args.checkpoint_dir, model.model_name)
+    os.makedirs(model_dir, exist_ok=True)
+    state = {"step": 0, "worse_epochs": 0, "epochs": 0, "best_loss": np.inf, "best_epoch": 0}
+    ck_path = os.path.join(model_dir, 'checkpoint')
+    if args.load_model is not None and os.path.isfile(args.load_model):
+        state = load_model(model, optimizer, args.load_model, args.use_cuda, device, scheduler)
+    epoch = state["epochs"]
+    while (state["worse_epochs"] < args.patience or epoch < args.min_n_epochs) and not (args.epochs and epoch >= args.epochs):
+        epoch += 1
+        state["epochs"] += 1
+        model.train()
+        train_loss = 0.0
+        t0 = time.time()
+        for i, (x, target) in enumerate(tr_data):
+            optimizer.zero_grad()
+            loss = seld_loss(x.to(device), target.to(device), model, criterion_sed, criterion_doa, args)
+            loss.backward()
+            optimizer.step()
+            state["step"] += 1
+            train_loss += (loss.detach() - train_loss) / (i + 1)
+            if args.max_steps and state["step"] >= args.max_steps:
+                break
+        val_loss = evaluate(model, device, criterion_sed, criterion_doa, val_data, args)
+        if scheduler is not None and optimizer.param_groups[0]['lr'] > args.min_lr:
+            scheduler.step()
+        print(f"epoch {epoch}: train {float(train_loss):.5f} val {val_loss:.5f} lr {optimizer.param_groups[0]['lr']:.2e} "
+              f"({time.time() - t0:.1f}s)")
+        if val_loss >= state["best_loss"]:
+            state["worse_epochs"] += 1
+        else:
+            state["worse_epochs"], state["best_epoch"], state["best_loss"] = 0, epoch, val_loss
+            save_model(model, optimizer, state, ck_path + '_best_model', scheduler)
+        save_model(model, optimizer, state, ck_path, scheduler)
+        if args.max_steps and state["step"] >= args.max_steps:
+            break
+    return state
+
+
+if __name__ == '__main__':
+    args = parse_args(sys.argv[1:])
+    main(args)

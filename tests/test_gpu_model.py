@@ -1,0 +1,162 @@
+"""Whole-model parity of the HIP path (through the C ABI) against the reference fixtures and the oracle.
+Tolerance: north_star asks 1e-3 absolute on (sed, doa); we also require 1e-3 * max|ref| on every
+intermediate tap and on the pre-activation logits (SURVEY App. C caveat)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import seld_oracle as O
+from tests.golden.cases import MODEL_CASES, train_target
+from tests.helpers import build_model, pkg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _np(t):
+    return t.detach().cpu().double().numpy()
+
+
+def _close(got, ref, rel=1e-3, what="", floor=1e-6):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(float(np.abs(ref).max()), floor)
+    err = float(np.abs(got - ref).max())
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _prepared(case):
+    m = build_model(case)
+    O.closed_form_fill_(list(m.state_dict().items()))
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("case", MODEL_CASES, ids=[c["name"] for c in MODEL_CASES])
+def test_eval_forward_matches_reference(case, golden):
+    g = golden("model_" + case["name"])
+    m = _prepared(case).eval()
+    x = O.closed_form_input((case["B"], case["input_channels"], case["freq_dim"], case["time_dim"])).to(DEV)
+    taps = {}
+    hooks = []
+    M = pkg().model
+
+    def mk(nm):
+        def hook(mod, inp, out):
+            taps[nm] = out
+        return hook
+    for nm, mod in m.named_modules():
+        if nm.endswith("tcn.conv1") or (".cnn." in nm and nm.count(".") == 2):
+            hooks.append(mod.register_forward_hook(mk(nm)))
+    hooks.append(m.sed[-2].register_forward_hook(mk("sed_logits")))
+    hooks.append(m.doa[-2].register_forward_hook(mk("doa_logits")))
+    with torch.no_grad():
+        sed, doa = m(x)
+    torch.cuda.synchronize()
+    assert np.abs(_np(sed) - g["sed"]).max() < 1e-3
+    assert np.abs(_np(doa) - g["doa"]).max() < 1e-3
+    for k in g:
+        if k.startswith("tap.") and k[4:] in taps:
+            _close(_np(taps[k[4:]]), g[k], what=k)
+
+
+@pytest.mark.parametrize("case", [c for c in MODEL_CASES if c.get("train")], ids=lambda c: c["name"])
+def test_resblock_taps_match_reference(case, golden):
+    """Per-block (residual, skip) outputs through the public ResBlock.forward."""
+    g = golden("model_" + case["name"])
+    m = _prepared(case).eval()
+    prefixes = ["branch_A", "branch_B"] if "branch_A.cnn.0" in "".join(g.keys()) else ["seld_block"]
+    for pre in prefixes:
+        blk = getattr(m, pre)
+        cnn_out = torch.from_numpy(g[f"tap.{pre}.cnn.2"]).to(DEV)
+        B, C, Fp, T = cnn_out.shape
+        x = cnn_out.reshape(B, C * Fp, T).contiguous()
+        with torch.no_grad():
+            for i, rb in enumerate(blk.tcn.ResBlocks):
+                x, skip = rb(x)
+                _close(_np(x), g[f"tap.{pre}.tcn.ResBlocks.{i}.residual"], what=f"res{i}")
+                _close(_np(skip), g[f"tap.{pre}.tcn.ResBlocks.{i}.skip"], what=f"skip{i}")
+        att_in = torch.from_numpy(g[f"tap.{pre}.tcn.conv1"]).to(DEV)       # (N, E, T)
+        with torch.no_grad():
+            a = blk.tcn.attention(att_in.permute(0, 2, 1).contiguous(), att_in.permute(0, 2, 1).contiguous(),
+                                  att_in.permute(0, 2, 1).contiguous())
+        _close(_np(a), g[f"tap.{pre}.tcn.attention"], what="attention")
+
+
+@pytest.mark.parametrize("case", [c for c in MODEL_CASES if c.get("train")], ids=lambda c: c["name"])
+def test_train_step_matches_reference(case, golden):
+    """forward (batch statistics) -> loss -> backward -> Adam: loss, every gradient checksum, selected full
+    gradients, parameter deltas and BatchNorm running statistics against the reference's step."""
+    g = golden("model_" + case["name"])
+    T = pkg().train
+    m = _prepared(case).train()
+    opt = T.FlatAdam(m.parameters(), lr=1e-4)
+    x = O.closed_form_input((case["B"], case["input_channels"], case["freq_dim"], case["time_dim"])).to(DEV)
+    target = train_target(case).to(DEV)
+    n_sed = int(case["output_classes"] * 3)
+    opt.zero_grad()
+    sed, doa = m(x)
+    loss = T.seld_loss_fn(sed, doa, target, n_sed, 1.0, 5.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.abs(_np(sed) - g["train.sed"]).max() < 1e-3
+    assert np.abs(_np(doa) - g["train.doa"]).max() < 1e-3
+    assert abs(loss.item() - float(g["train.loss"][0])) <= 1e-4 * max(1.0, abs(float(g["train.loss"][0])))
+    names = str(g["train.param_names"]).split("\n")
+    params = dict(m.named_parameters())
+    assert list(params.keys()) == names
+    cks = g["train.grad_checksums"]
+    before = {n: p.detach().clone() for n, p in params.items()}
+    numel = np.array([params[n].numel() for n in names], dtype=np.float64)
+    ref_rms = np.sqrt(np.nan_to_num(cks[:, 1]) / numel)
+    floor = 1e-4 * ref_rms.max()          # gradients below 1e-4 of the largest RMS are fp32 noise in both stacks
+    for i, n in enumerate(names):
+        gr = params[n].grad
+        if np.isnan(cks[i, 0]):
+            assert gr is None or float(gr.abs().max()) == 0.0, n
+            continue
+        got = np.array([gr.double().sum().item(), (gr.double() ** 2).sum().item()])
+        rms = max(ref_rms[i], floor)
+        assert abs(got[1] - cks[i, 1]) <= 4e-3 * rms * rms * numel[i], (n, got, cks[i])
+        assert abs(got[0] - cks[i, 0]) <= 2e-3 * rms * numel[i], (n, got, cks[i])
+    for k in g:
+        if k.startswith("train.grad."):
+            _close(_np(params[k[len("train.grad."):]].grad), g[k], what=k, floor=10 * floor)   # exact zeros of the reference (conv bias under BatchNorm) are fp32 cancellation noise here
+    opt.step()
+    torch.cuda.synchronize()
+    dck = g["train.delta_checksums"]
+    for i, n in enumerate(names):
+        if ref_rms[i] < 10 * floor:
+            continue      # gradient is (numerically) zero in the fp64 reference: Adam turns fp32 noise into +-lr steps
+        d = (params[n].detach() - before[n]).double()
+        got = np.array([d.sum().item(), (d ** 2).sum().item()])
+        # Adam's first step is lr * g / (|g| + 1e-8): elements whose gradient is at the fp32 noise level (|g| ~ 1e-8)
+        # move by up to lr in either stack, so allow three such elements on top of the relative tolerance;
+        # the kernel itself is checked exactly in test_gpu_ops.py::test_adam_flat_matches_oracle
+        assert abs(got[1] - dck[i, 1]) <= 5e-3 * dck[i, 1] + 3 * (1e-4) ** 2, (n, got, dck[i])
+    sd = m.state_dict()
+    rnames = str(g["train.running_names"]).split("\n")
+    rck = g["train.running_checksums"]
+    for i, n in enumerate(rnames):
+        v = sd[n].double()
+        got = np.array([v.sum().item(), (v ** 2).sum().item()])
+        assert np.allclose(got, rck[i], rtol=1e-4, atol=1e-6), (n, got, rck[i])
+
+
+def test_dropout_statistics_and_reuse():
+    """Train-mode dropout cannot match the CPU RNG; check keep-rate, scaling and that backward reuses the mask."""
+    H = pkg().hip_ops
+    torch.manual_seed(3)
+    x = torch.ones(1 << 20, device=DEV, requires_grad=True)
+    y = H.dropout(x, 0.3, True)
+    y.sum().backward()
+    keep = (y > 0).float().mean().item()
+    assert abs(keep - 0.7) < 5e-3
+    assert torch.allclose(y[y > 0], torch.full_like(y[y > 0], 1 / 0.7))
+    assert torch.equal(x.grad > 0, y > 0)
+    mask = H.channel_dropout_mask(64, 128, 0.5, torch.device(DEV))
+    assert abs((mask > 0).float().mean().item() - 0.5) < 0.03
+    assert set(mask.unique().tolist()) <= {0.0, 2.0}
+
+
+def test_smoke_entry():
+    pkg().selftest.smoke()

@@ -1,0 +1,273 @@
+"""Per-kernel GPU checks of the non-convolution ops against the oracle / torch-CPU fp64 and the fixtures."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import seld_oracle as O
+from tests.golden.cases import OP_CASES, op_cotangent, op_inputs
+from tests.helpers import pkg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(got, ref, rel=1e-4, what=""):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    err = float(np.abs(got - ref).max())
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+LIN_CASES = [c for c in OP_CASES if "lin" in c["kind"]]
+
+
+@pytest.mark.parametrize("case", LIN_CASES, ids=[c["name"] for c in LIN_CASES])
+def test_linear_matches_fixture(case, golden):
+    H, L = pkg().hip_ops, pkg()._lib
+    g = golden("ops")
+    x, ws, bias = op_inputs(case)
+    xd = x.to(DEV).requires_grad_(True)
+    wd = [w.to(DEV).requires_grad_(True) for w in ws]
+    bd = bias.to(DEV).requires_grad_(True) if bias is not None else None
+    kind = L.SELD_LIN_DUALQ if case["kind"].startswith("dq") else L.SELD_LIN_QUAT
+    y = H.hyper_linear(xd, wd, bd, kind)
+    (y * op_cotangent(y.shape).to(DEV)).sum().backward()
+    n = case["name"]
+    _close(y, g[n + ".y"], what="y")
+    _close(xd.grad, g[n + ".dx"], what="dx")
+    for i, w in enumerate(wd):
+        _close(w.grad, g[f"{n}.dw{i}"], rel=5e-4, what=f"dw{i}")   # signed 4/8-block folds of fp32 sums cancel
+    if bd is not None:
+        _close(bd.grad, g[n + ".dbias"], what="dbias")
+
+
+def test_real_linear_large():
+    hnn = pkg().hip_nn
+    torch.manual_seed(0)
+    lin = hnn.Linear(384, 126).to(DEV)
+    x = torch.randn(3, 70, 384, device=DEV, requires_grad=True)
+    y = lin(x)
+    cot = torch.randn_like(y)
+    (y * cot).sum().backward()
+    x64 = x.detach().cpu().double().requires_grad_(True)
+    w64 = lin.weight.detach().cpu().double().requires_grad_(True)
+    b64 = lin.bias.detach().cpu().double().requires_grad_(True)
+    yr = F.linear(x64, w64, b64)
+    (yr * cot.cpu().double()).sum().backward()
+    _close(y, yr)
+    _close(x.grad, x64.grad)
+    _close(lin.weight.grad, w64.grad)
+    _close(lin.bias.grad, b64.grad)
+
+
+@pytest.mark.parametrize("shape,act", [((4, 24, 100), 2), ((2, 16, 12, 64), 1), ((3, 8, 77), 0), ((2, 8, 5, 9), 3)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act(shape, act, training):
+    H, hnn = pkg().hip_ops, pkg().hip_nn
+    torch.manual_seed(1)
+    C = shape[1]
+    bn = (hnn.BatchNorm1d if len(shape) == 3 else hnn.BatchNorm2d)(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+    ref = (torch.nn.BatchNorm1d if len(shape) == 3 else torch.nn.BatchNorm2d)(C).double()
+    ref.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.cpu() for k, v in bn.state_dict().items()})
+    bn.train(training)
+    ref.train(training)
+    x = (torch.randn(shape) * 1.3 + 0.4)
+    xd = x.to(DEV).requires_grad_(True)
+    y = H.bn_act(xd, bn, act)
+    cot = torch.randn(shape)
+    (y * cot.to(DEV)).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    z = ref(x64)
+    yr = [z, torch.relu(z), torch.tanh(z), torch.sigmoid(z)][act]
+    (yr * cot.double()).sum().backward()
+    _close(y, yr, what="y")
+    _close(xd.grad, x64.grad, rel=2e-4, what="dx")
+    _close(bn.weight.grad, ref.weight.grad, rel=2e-4, what="dgamma")
+    _close(bn.bias.grad, ref.bias.grad, rel=2e-4, what="dbeta")
+    _close(bn.running_mean, ref.running_mean, what="running_mean")
+    _close(bn.running_var, ref.running_var, what="running_var")
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_gate(training):
+    H, hnn = pkg().hip_ops, pkg().hip_nn
+    torch.manual_seed(2)
+    N, C, T = 3, 16, 52
+    bf, bg = hnn.BatchNorm1d(C).to(DEV), hnn.BatchNorm1d(C).to(DEV)
+    for b in (bf, bg):
+        with torch.no_grad():
+            b.weight.uniform_(0.5, 1.5); b.bias.uniform_(-0.5, 0.5)
+            b.running_mean.uniform_(-0.2, 0.2); b.running_var.uniform_(0.5, 1.5)
+        b.train(training)
+    rf, rg = torch.nn.BatchNorm1d(C).double(), torch.nn.BatchNorm1d(C).double()
+    for r, b in ((rf, bf), (rg, bg)):
+        r.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.cpu() for k, v in b.state_dict().items()})
+        r.train(training)
+    yf, yg = torch.randn(N, C, T), torch.randn(N, C, T)
+    mask = (torch.rand(N * C) > 0.5).float() * 2.0
+    a, b_ = yf.to(DEV).requires_grad_(True), yg.to(DEV).requires_grad_(True)
+    y = H.gate(a, b_, bf, bg, mask.to(DEV))
+    cot = torch.randn(N, C, T)
+    (y * cot.to(DEV)).sum().backward()
+    a64, b64 = yf.double().requires_grad_(True), yg.double().requires_grad_(True)
+    yr = torch.tanh(rf(a64)) * torch.sigmoid(rg(b64)) * mask.double().view(N, C, 1)
+    (yr * cot.double()).sum().backward()
+    _close(y, yr, what="y")
+    _close(a.grad, a64.grad, rel=2e-4, what="dyf")
+    _close(b_.grad, b64.grad, rel=2e-4, what="dyg")
+    _close(bf.weight.grad, rf.weight.grad, rel=2e-4)
+    _close(bf.bias.grad, rf.bias.grad, rel=2e-4)
+    _close(bg.weight.grad, rg.weight.grad, rel=2e-4)
+    _close(bg.bias.grad, rg.bias.grad, rel=2e-4)
+    _close(bf.running_var, rf.running_var)
+    y2 = H.gate_plain(a.detach(), b_.detach())
+    _close(y2, torch.tanh(yf.double()) * torch.sigmoid(yg.double()), what="plain")
+
+
+@pytest.mark.parametrize("shape,ph,pw", [((2, 6, 16, 40), 8, 1), ((2, 6, 4, 40), 2, 1), ((3, 5, 64), 1, 2), ((2, 3, 9, 10), 2, 3)])
+def test_maxpool(shape, ph, pw):
+    H = pkg().hip_ops
+    torch.manual_seed(3)
+    x = torch.randn(shape)
+    xd = x.to(DEV).requires_grad_(True)
+    y = H.maxpool(xd, ph, pw)
+    cot = torch.randn(y.shape)
+    (y * cot.to(DEV)).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    yr = F.max_pool1d(x64, pw) if len(shape) == 3 else F.max_pool2d(x64, (ph, pw))
+    (yr * cot.double()).sum().backward()
+    _close(y, yr, rel=0)
+    _close(xd.grad, x64.grad, rel=0)
+
+
+def test_mha_module_matches_fixture(golden):
+    g = golden("mha")
+    M = pkg().model
+    E, T, N = 48, 20, 2
+    mha = M.MultiHeadAttention(E, 8)
+    O.closed_form_fill_(list(mha.state_dict().items()), amp=0.6)
+    mha = mha.to(DEV)
+    x = O.closed_form_input((N, T, E)).to(DEV).requires_grad_(True)
+    y = mha(x, x, x)
+    (y * O.closed_form_input(tuple(y.shape)).flip(1).to(DEV)).sum().backward()
+    _close(y, g["y"], rel=2e-4, what="y")
+    _close(x.grad, g["dx"], rel=5e-4, what="dx")
+    _close(mha.queries.weight.grad, g["dwq"], rel=5e-4, what="dwq")
+    _close(mha.keys.weight.grad, g["dwk"], rel=5e-4, what="dwk")
+    _close(mha.values.weight.grad, g["dwv"], rel=5e-4, what="dwv")
+    _close(mha.fc_out.weight.grad, g["dwo"], rel=5e-4, what="dwo")
+    _close(mha.fc_out.bias.grad, g["dbo"], rel=5e-4, what="dbo")
+
+
+@pytest.mark.parametrize("N,H_,hd,T", [(2, 8, 48, 256), (1, 8, 16, 100), (1, 4, 64, 130), (2, 8, 2, 33), (1, 2, 48, 600)])
+def test_mha_core_vs_sdpa(N, H_, hd, T):
+    """Flash kernel vs torch's scaled_dot_product_attention in fp64 on the CPU, incl. a spiky row that forces
+    the online-softmax rescale across key tiles (guide rule 26)."""
+    H = pkg().hip_ops
+    gen = torch.Generator().manual_seed(5)
+    E = H_ * hd
+    q, k, v = (torch.randn(N, E, T, generator=gen) for _ in range(3))
+    k[:, :, T // 2 + 7] *= 6.0          # a key far above the rest, in a later tile
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = H.mha_core(qd, kd, vd, H_)
+    cot = torch.randn(N, E, T, generator=gen)
+    (out * cot.to(DEV)).sum().backward()
+
+    def heads(t):
+        return t.double().view(N, H_, hd, T).permute(0, 1, 3, 2)    # (N, H, T, hd)
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    o = F.scaled_dot_product_attention(heads(q64), heads(k64), heads(v64))
+    o = o.permute(0, 1, 3, 2).reshape(N, E, T)
+    (o * cot.double()).sum().backward()
+    _close(out, o, rel=2e-4, what="out")
+    _close(qd.grad, q64.grad, rel=5e-4, what="dq")
+    _close(kd.grad, k64.grad, rel=5e-4, what="dk")
+    _close(vd.grad, v64.grad, rel=5e-4, what="dv")
+
+
+def test_loss_kernel():
+    H = pkg().hip_ops
+    gen = torch.Generator().manual_seed(6)
+    sed = torch.rand(4, 8, 42, generator=gen).clamp(1e-4, 1 - 1e-4)
+    sed[0, 0, 0], sed[0, 0, 1] = 0.0, 1.0        # exercises the log clamp at -100
+    doa = torch.rand(4, 8, 126, generator=gen) * 2 - 1
+    tgt = torch.cat(((torch.rand(4, 8, 42, generator=gen) < 0.1).float(), torch.rand(4, 8, 126, generator=gen) * 2 - 1), 2)
+    a, b = sed.to(DEV).requires_grad_(True), doa.to(DEV).requires_grad_(True)
+    loss = H.seld_loss(a, b, tgt.to(DEV), 1.0, 5.0)
+    loss.backward()
+    s64, d64 = sed.double().requires_grad_(True), doa.double().requires_grad_(True)
+    ref = O.seld_loss(s64, d64, tgt.double(), 42, 1.0, 5.0)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    gs, gr = a.grad.cpu().double(), s64.grad
+    finite = torch.isfinite(gr) & (gr.abs() < 1e6)
+    _close(gs[finite], gr[finite], rel=1e-4)
+    _close(b.grad, d64.grad, rel=1e-4)
+
+
+def test_adam_flat_matches_oracle():
+    H = pkg().hip_ops
+    gen = torch.Generator().manual_seed(7)
+    n = 10007
+    p = torch.randn(n, generator=gen)
+    m = torch.zeros(n)
+    v = torch.zeros(n)
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    p64, m64, v64 = p.double(), m.double(), v.double()
+    for step in range(1, 4):
+        g = torch.randn(n, generator=gen) * (10.0 ** torch.randint(-6, 1, (n,), generator=gen).float())
+        H.adam_flat_step(pd, g.to(DEV), md, vd, step, lr=1e-4)
+        p64, m64, v64 = O.adam_step(p64, g.double(), m64, v64, step)
+    _close(pd, p64, rel=1e-6)
+    _close(md, m64, rel=1e-4)
+    _close(vd, v64, rel=1e-4)
+
+
+def test_transpose_and_act():
+    H, L = pkg().hip_ops, pkg()._lib
+    x = torch.randn(3, 37, 50)
+    y = H.transpose12(x.to(DEV))
+    assert torch.equal(y.cpu(), x.permute(0, 2, 1).contiguous())
+    for act, fn in ((L.SELD_ACT_RELU, torch.relu), (L.SELD_ACT_TANH, torch.tanh), (L.SELD_ACT_SIGMOID, torch.sigmoid)):
+        xd = x.to(DEV).requires_grad_(True)
+        yy = H.act(xd, act)
+        yy.sum().backward()
+        x64 = x.double().requires_grad_(True)
+        r = fn(x64)
+        r.sum().backward()
+        _close(yy, r)
+        _close(xd.grad, x64.grad)
+
+
+def test_stft_matches_fixture_and_oracle(golden):
+    H = pkg().hip_ops
+    g = golden("stft")
+    n = np.arange(6400)
+    x = np.stack([np.sin(2 * np.pi * (100 + 37 * c) * n / 32000) + 0.1 * np.sin(0.013 * n * (c + 1)) for c in range(8)])
+    xd = torch.from_numpy(x).float().to(DEV)
+    for key, nov, ph in (("magphase_112", 112, True), ("mag_112", 112, False), ("magphase_128", 128, True)):
+        out = H.stft_magphase(xd, 512, nov, ph).cpu().double().numpy()
+        ref = g[key]
+        assert out.shape == ref.shape
+        C = 8
+        assert np.abs(out[:C] - ref[:C]).max() < 2e-6 * max(1.0, np.abs(ref[:C]).max()) + 2e-7
+        if ph:
+            mask = ref[:C] > 1e-4
+            dphi = np.angle(np.exp(1j * (out[C:] - ref[C:])))
+            assert np.abs(dphi[mask]).max() < 2e-3
+    # a longer clip against the closed-form oracle (frames not a multiple of the workgroup's 16)
+    rng = np.random.RandomState(0)
+    xl = rng.randn(3, 40000)
+    out = H.stft_magphase(torch.from_numpy(xl).float().to(DEV), 512, 112, True).cpu().double().numpy()
+    ref = O.spectrum_fast(xl.astype(np.float32).astype(np.float64), 512, 112, output_phase=True)
+    assert out.shape == ref.shape
+    assert np.abs(out[:3] - ref[:3]).max() < 1e-5
