@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Train-step benchmark of the DualQ-SELD-TCN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1]
+
+One step = zero_grad -> forward -> BCE + 5*MSE -> backward -> (all-reduce) -> Adam on one synthetic
+minibatch resident in HBM.  Prints ONE JSON line (rank 0) with the whole-job samples/s, the
+roofline of the dominant kernel measured with HIP events inside the timed region, and the CPU baseline
+(the oracle timed on the host cores, rank 0, N = 1 only).
+
+For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: one process
+per GPU, RCCL all-reduce of the flat gradient buffer, weak scaling (per-GPU batch fixed).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "sound-event-localization-and-detection_amd"
+
+# BASELINE.json configs at the synthetic benchmark shape F=128, T=512 (F=128 needs U = L)
+WORKLOADS = {
+    "c1": dict(name="SELD-TCN-S1-PHI_8ch (real)", domain="R", domain_classifier="R", input_channels=8, batch=2,
+               cnn_filters=[64] * 3, G=128, U=64, V=[128, 128], fc_layers=[128]),
+    "c2": dict(name="QSELD-TCN-S1-PHI_parallel_8ch", domain="Q", domain_classifier="R", input_channels=8, batch=32,
+               cnn_filters=[64] * 3, G=128, U=64, V=[128, 128], fc_layers=[128]),
+    "c3": dict(name="DQSELD-TCN-S1-PHI_8ch", domain="DQ", domain_classifier="DQ", input_channels=8, batch=32,
+               cnn_filters=[192] * 3, G=384, U=192, V=[384, 384], fc_layers=[384]),
+}
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_FP32_MFMA_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense
+
+
+def model_kwargs(w, freq=128, time_dim=512):
+    return dict(time_dim=time_dim, freq_dim=freq, input_channels=w["input_channels"], output_classes=14,
+                domain=w["domain"], domain_classifier=w["domain_classifier"], cnn_filters=w["cnn_filters"],
+                kernel_size_cnn_blocks=3, pool_size=[[8, 2], [8, 2], [2, 2]], pool_time="TCN", D=[10],
+                dilation_mode="fibonacci", G=w["G"], U=w["U"], kernel_size_dilated_conv=3, spatial_dropout_rate=0.5,
+                V=w["V"], V_kernel_size=3, fc_layers=w["fc_layers"], fc_activations="linear", fc_dropout="Last",
+                dropout_perc=0.3, class_overlaps=3, use_bias_conv=0, use_bias_linear=1, batch_norm="BN")
+
+
+def cpu_baseline(w, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference's algorithm, `assembled` = one real conv per layer exactly as
+    quaternion_ops.py:125-147 does) timed on this host: same step definition, dropout on, bounded sample."""
+    from oracle import seld_oracle as O
+    import numpy as np
+    pkg = importlib.import_module(PKG)
+    batch = min(w["batch"], 4)
+    kw = model_kwargs(w)
+    np.random.seed(1)
+    torch.manual_seed(1)
+    m = pkg.model.SELD_Model(**kw)           # host-side construction only (weights); never run on the CPU
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    leaves = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    cfg = O.SeldConfig(**kw)
+    opt = torch.optim.Adam(leaves, lr=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(batch, w["input_channels"], 128, 512, generator=g)
+    target = torch.cat(((torch.rand(batch, 64, 42, generator=g) < 0.1).float(),
+                        torch.rand(batch, 64, 126, generator=g) * 2 - 1), 2)
+
+    def step():
+        opt.zero_grad()
+        sed, doa = O.seld_forward(sd, cfg, x, train=True, mode="assembled", dropout=True)
+        loss = O.seld_loss(sed, doa, target, 42)
+        loss.backward()
+        opt.step()
+    step()                                    # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 8):
+        step()
+        n += 1
+    dt = time.time() - t0
+    return dict(value=round(batch * n / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} train steps of the same workload at batch {batch} (oracle, torch-CPU fp32, dropout on)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    pkg = importlib.import_module(PKG)
+    H, T, DP = pkg.hip_ops, pkg.train, pkg.dp
+    rank, local, world = DP.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    w = WORKLOADS[args.workload]
+    batch = args.batch or w["batch"]
+    import numpy as np
+    np.random.seed(1)
+    torch.manual_seed(1)
+    model = pkg.model.SELD_Model(**model_kwargs(w)).to(dev).train()
+    opt = T.FlatAdam(model.parameters(), lr=1e-4)
+    DP.broadcast_parameters(opt.flat_param)
+    sync = DP.FlatGradSync(flat_grad=opt.flat_grad)
+    x, target = T.synthetic_batch(batch, w["input_channels"], 128, 512, 42, 1234 + rank, dev)
+
+    def step():
+        return DP.dp_train_step(model, opt, sync, x, target, 42, T.seld_loss_fn)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    H.kernel_timer.reset()
+    H.kernel_timer.active = not args.no_kernel_timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    H.kernel_timer.active = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "train-step samples/sec (8ch x 128mel x 512T)", "value": round(batch * world * args.steps / elapsed, 3),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['name']} train step, F=128 T=512 (U=L={w['U']}, SURVEY F3), "
+                                   f"batch {batch}/GPU, random-init weights", "global_batch": batch * world,
+                       "parallelism": f"dp{world}"},
+            "loss": round(final_loss, 6),
+        }
+        summ = H.kernel_timer.summary()
+        if summ:
+            per = []
+            for label, d in summ.items():
+                tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                gb = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                per.append(dict(kernel=label, calls_per_step=d["calls"] / args.steps, ms_per_step=round(d["ms"] / args.steps, 4),
+                                avg_us=round(d["ms"] / d["calls"] * 1e3, 2), tflops=round(tf, 2), gbs=round(gb, 1)))
+            per.sort(key=lambda r: -r["ms_per_step"])
+            dom = per[0]
+            d = summ[dom["kernel"]]
+            # roof that bounds the dominant kernel: compare time at each peak
+            t_hbm = d["bytes"] / (PEAK_HBM_GBS * 1e9)
+            t_mfma = d["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            if t_hbm >= t_mfma:
+                roof = dict(bound="hbm", achieved=dom["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=round(dom["gbs"] / PEAK_HBM_GBS, 4))
+            else:
+                roof = dict(bound="mfma", achieved=dom["tflops"], peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4))
+            roof.update(kernel=dom["kernel"], avg_launch_us=dom["avg_us"], launches_per_step=dom["calls_per_step"],
+                        traffic=None)
+            out["roofline"] = roof
+            out["conv_kernels"] = per[:8]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,11 @@ int seld_hc_conv_bwd_weight(const seld_conv_desc* d, const float* x, const float
                             float* const dw[8], float* dbias /* nullable */,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* Diagnostics: label of the kernel symbol a call would launch ("hc_conv_kernel<4, 4, 1, 3>"), so that
+ * HIP-event timings taken by the caller can be matched with rocprofv3's per-kernel statistics.
+ * which: 0 forward, 1 data gradient, 2 weight gradient.  buflen >= 48. */
+int seld_hc_conv_kernel_label(const seld_conv_desc* d, int32_t which, char* buf, int32_t buflen);
+
 /* ------------------------------------------------------------------------------------------
  * Hypercomplex / real linear  y[rows, out] = x[rows, in] @ M + b.
  *   SELD_LIN_REAL   : torch.nn.Linear, weight (out, in)                 (model.py:23,439,454,458)

@@ -334,8 +334,9 @@ def _bn(sd, prefix, x, train, stats_out):
                       sd[prefix + ".running_var"], train, stats_out=stats_out, name=prefix)
 
 
-def res_block(sd, prefix, cfg: SeldConfig, x, dilation, train, mode, stats_out=None):
-    """ResBlock.forward, model.py:109-132 (dropout disabled: RNG parity is impossible)."""
+def res_block(sd, prefix, cfg: SeldConfig, x, dilation, train, mode, stats_out=None, dropout=False):
+    """ResBlock.forward, model.py:109-132.  `dropout` (CPU-baseline timing only: RNG parity with the GPU is
+    impossible, so every parity check runs with it off) enables the Dropout1d of :127-128."""
     use_bn = cfg.batch_norm in {"BN", "BN_on_TCN", "BNonTCN"}
     k = cfg.kernel_size_dilated_conv
     pad = int(((k - 1) * dilation) / 2)
@@ -347,16 +348,18 @@ def res_block(sd, prefix, cfg: SeldConfig, x, dilation, train, mode, stats_out=N
         yf = _bn(sd, prefix + ".batch_filter2", yf, train, stats_out)
         yg = _bn(sd, prefix + ".batch_gate2", yg, train, stats_out)
     y = torch.tanh(yf) * torch.sigmoid(yg)
+    if dropout and cfg.spatial_dropout_rate:
+        y = F.dropout1d(y, cfg.spatial_dropout_rate, training=True)
     skip = _conv_layer(sd, prefix + ".conv2_skip", cfg.algebra, y, 1, 0, 1, mode)
     res = _conv_layer(sd, prefix + ".conv2_residual", cfg.algebra, y, 1, 0, 1, mode)
     return x + res, skip
 
 
-def tc_block(sd, prefix, cfg: SeldConfig, x, train, mode, taps=None, stats_out=None):
+def tc_block(sd, prefix, cfg: SeldConfig, x, train, mode, taps=None, stats_out=None, dropout=False):
     """TC_Block.forward, model.py:204-232."""
     skip_sum = None
     for bi, d in enumerate(dilations(cfg)):
-        x, skip = res_block(sd, f"{prefix}.ResBlocks.{bi}", cfg, x, d, train, mode, stats_out)
+        x, skip = res_block(sd, f"{prefix}.ResBlocks.{bi}", cfg, x, d, train, mode, stats_out, dropout)
         skip_sum = skip if skip_sum is None else skip_sum + skip
         if taps is not None:
             taps[f"{prefix}.ResBlocks.{bi}.residual"] = x
@@ -384,8 +387,8 @@ def tc_block(sd, prefix, cfg: SeldConfig, x, train, mode, taps=None, stats_out=N
     return out
 
 
-def conv_tc_block(sd, prefix, cfg: SeldConfig, x, train, mode, taps=None, stats_out=None):
-    """ConvTC_Block.forward, model.py:297-322 (dropout disabled)."""
+def conv_tc_block(sd, prefix, cfg: SeldConfig, x, train, mode, taps=None, stats_out=None, dropout=False):
+    """ConvTC_Block.forward, model.py:297-322."""
     use_bn = cfg.batch_norm in {"BN", "BN_on_CNN", "BNonCNN"}
     for i, p in enumerate(cfg.pool_size[:len(cfg.cnn_filters)]):
         x = _conv_layer(sd, f"{prefix}.cnn.{i}.0", cfg.algebra, x, 1, 1, 1, mode)
@@ -394,16 +397,18 @@ def conv_tc_block(sd, prefix, cfg: SeldConfig, x, train, mode, taps=None, stats_
         x = torch.relu(x)
         pool = [p[0], p[1]] if cfg.pool_time == "CNN" else [p[0], 1]
         x = F.max_pool2d(x, pool)
+        if dropout and cfg.dropout_perc:
+            x = F.dropout(x, cfg.dropout_perc, training=True)
         if taps is not None:
             taps[f"{prefix}.cnn.{i}"] = x
     B = x.shape[0]
     x = x.permute(0, 3, 1, 2).reshape(B, x.shape[3], -1).permute(0, 2, 1)
-    x = tc_block(sd, prefix + ".tcn", cfg, x, train, mode, taps, stats_out)
+    x = tc_block(sd, prefix + ".tcn", cfg, x, train, mode, taps, stats_out, dropout)
     return x.permute(0, 2, 1)
 
 
-def _head(sd, name, cfg: SeldConfig, x, mode):
-    """model.py:430-459 (dropout disabled)."""
+def _head(sd, name, cfg: SeldConfig, x, mode, dropout=False):
+    """model.py:430-459."""
     idx = 0
     for _ in cfg.fc_layers:
         p = f"{name}.{idx}"
@@ -418,15 +423,19 @@ def _head(sd, name, cfg: SeldConfig, x, mode):
             x = torch.relu(x)
             idx += 1
         if cfg.fc_dropout in {"all", "ALL", "True"}:
+            if dropout and cfg.dropout_perc:
+                x = F.dropout(x, cfg.dropout_perc, training=True)
             idx += 1
     if cfg.fc_dropout in {"last", "Last", "LAST"}:
+        if dropout and cfg.dropout_perc:
+            x = F.dropout(x, cfg.dropout_perc, training=True)
         idx += 1
     p = f"{name}.{idx}"
     return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
 
 
 def seld_forward(sd: Dict[str, torch.Tensor], cfg: SeldConfig, x, train=False, mode="assembled",
-                 taps: Optional[dict] = None, stats_out: Optional[dict] = None):
+                 taps: Optional[dict] = None, stats_out: Optional[dict] = None, dropout: bool = False):
     """SELD_Model.forward, model.py:461-480.  `sd` uses the reference's state-dict key names
     (SURVEY App. B).  `train=True` selects batch statistics in BatchNorm; dropout is always off."""
     if cfg.two_stream:
@@ -436,13 +445,13 @@ def seld_forward(sd: Dict[str, torch.Tensor], cfg: SeldConfig, x, train=False, m
         else:
             h = cfg.input_channels // 2
             xa, xb = x[:, :h], x[:, h:]
-        a = conv_tc_block(sd, "branch_A", cfg, xa, train, mode, taps, stats_out)
-        b = conv_tc_block(sd, "branch_B", cfg, xb, train, mode, taps, stats_out)
+        a = conv_tc_block(sd, "branch_A", cfg, xa, train, mode, taps, stats_out, dropout)
+        b = conv_tc_block(sd, "branch_B", cfg, xb, train, mode, taps, stats_out, dropout)
         feat = torch.cat((a, b), 2)
     else:
-        feat = conv_tc_block(sd, "seld_block", cfg, x, train, mode, taps, stats_out)
-    sed_logits = _head(sd, "sed", cfg, feat, mode)
-    doa_logits = _head(sd, "doa", cfg, feat, mode)
+        feat = conv_tc_block(sd, "seld_block", cfg, x, train, mode, taps, stats_out, dropout)
+    sed_logits = _head(sd, "sed", cfg, feat, mode, dropout)
+    doa_logits = _head(sd, "doa", cfg, feat, mode, dropout)
     if taps is not None:
         taps["feat"] = feat
         taps["sed_logits"] = sed_logits

@@ -18,6 +18,7 @@
 // with 4 consecutive positions of one channel -> 16-byte coalesced stores along T / W.
 // LDS images are [k/4][row][4] so one ds_read_b128 feeds four MFMAs (conflict-free, see
 // DESIGN.md), staging is register double-buffered with one barrier per 16-deep K step.
+#include <stdio.h>
 #include "common.h"
 
 namespace seld {
@@ -521,12 +522,21 @@ static void launch_conv(const ConvP& p, hipStream_t st) {
     else hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 0, 0>), grid, dim3(256), 0, st, p);
 }
 
+// tile selection shared by the launcher and by seld_hc_conv_kernel_label
+static void pick_tiles(int C, int* ct, int* pt) {
+    *pt = 4;
+    if (C <= 16) *ct = 1;
+    else if (C <= 32) *ct = 2;
+    else if (C % 96 == 0 && C % 64 != 0) *ct = 6;
+    else *ct = 4;
+}
+
 static int run_conv(ConvP& p, hipStream_t st) {
-    // channel tile: largest of 96/64 that divides well; small problems use 32/16
-    const int C = p.Cdst;
-    if (C <= 16) launch_conv<1, 4>(p, st);
-    else if (C <= 32) launch_conv<2, 4>(p, st);
-    else if (C % 96 == 0 && C % 64 != 0) launch_conv<6, 4>(p, st);
+    int ct, pt;
+    pick_tiles(p.Cdst, &ct, &pt);
+    if (ct == 1) launch_conv<1, 4>(p, st);
+    else if (ct == 2) launch_conv<2, 4>(p, st);
+    else if (ct == 6) launch_conv<6, 4>(p, st);
     else launch_conv<4, 4>(p, st);
     return check_launch();
 }
@@ -670,4 +680,21 @@ extern "C" int seld_hc_conv_bwd_weight(const seld_conv_desc* d, const float* x, 
         rc = check_launch();
     }
     return rc;
+}
+
+// Label of the kernel symbol a call would launch ("hc_conv_kernel<CT,PT,KH,KW>" as rocprofv3 prints the
+// template arguments); which = 0 forward, 1 data gradient, 2 weight gradient.
+extern "C" int seld_hc_conv_kernel_label(const seld_conv_desc* d, int32_t which, char* buf, int32_t buflen) {
+    int rc = validate(d);
+    if (rc || !buf || buflen < 48) return SELD_EINVAL;
+    int kh = d->k[0], kw = d->k[1];
+    if (!((kh == 1 && kw == 1) || (kh == 1 && kw == 3) || (kh == 3 && kw == 3))) kh = kw = 0;
+    if (which == 2) {
+        snprintf(buf, buflen, "hc_wgrad_kernel<2, 2, %d, %d>", kh, kw);
+    } else {
+        int ct, pt;
+        pick_tiles(which == 0 ? d->Cout : d->Cin, &ct, &pt);
+        snprintf(buf, buflen, "hc_conv_kernel<%d, %d, %d, %d>", ct, pt, kh, kw);
+    }
+    return SELD_OK;
 }

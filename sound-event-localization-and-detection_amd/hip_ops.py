@@ -9,6 +9,74 @@ import torch
 from . import _lib as L
 
 
+class KernelTimer:
+    """HIP-event timing of individual conv launches on the stream they are enqueued on (bench.py's roofline
+    leg).  Inactive by default: then the wrappers below add nothing to the launch path."""
+
+    def __init__(self):
+        self.active = False
+        self.records = []      # (label, start_event, end_event, flops, bytes)
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        """label -> dict(calls, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        out = {}
+        for label, e0, e1, fl, by in self.records:
+            d = out.setdefault(label, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+kernel_timer = KernelTimer()
+
+
+def conv_work(desc, which):
+    """Algorithmic flops / bytes of one conv call: x and y once, COMPONENT weights once, structured
+    flops (48 of 64 blocks for the dual quaternion, all 16 for the quaternion).  which: 0 fwd, 1 dgrad, 2 wgrad."""
+    A = desc.algebra
+    o = conv_out_shape(desc)
+    s_in = desc.in_[0] * desc.in_[1]
+    s_out = o[0] * o[1]
+    K = desc.k[0] * desc.k[1]
+    nb = {1: 1, 4: 16, 8: 48}[A]
+    blk = (desc.Cout // A) * (desc.Cin // A)
+    flops = 2.0 * desc.N * s_out * K * nb * blk
+    by = 4.0 * (desc.N * desc.Cin * s_in + desc.N * desc.Cout * s_out + A * blk * K)
+    return flops, by
+
+
+def _label(desc, which):
+    buf = ctypes.create_string_buffer(64)
+    L.check(L.lib().seld_hc_conv_kernel_label(ctypes.byref(desc), which, buf, 64), "seld_hc_conv_kernel_label")
+    return buf.value.decode()
+
+
+class _Timed:
+    def __init__(self, desc, which):
+        self.on = kernel_timer.active
+        if self.on:
+            self.desc, self.which = desc, which
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            fl, by = conv_work(self.desc, self.which)
+            kernel_timer.records.append((_label(self.desc, self.which), self.e0, self.e1, fl, by))
+        return False
+
+
 def _req(t, name):
     if t is None:
         return None
@@ -65,9 +133,10 @@ def conv_fwd(desc, x, ws, bias=None, out=None, epilogue=0, addend=None, stats=No
     bias = _req(bias, "bias")
     o = conv_out_shape(desc)
     y = out if out is not None else torch.empty(_y_shape(desc, o), device=x.device, dtype=torch.float32)
-    L.check(L.lib().seld_hc_conv_fwd_ex(ctypes.byref(desc), L.ptr(x), L.ptr_array8(ws), L.ptr(bias), L.ptr(y),
-                                        ctypes.c_int32(epilogue), L.ptr(_req(addend, "addend")), L.ptr(stats),
-                                        L.current_stream()), "seld_hc_conv_fwd")
+    with _Timed(desc, 0):
+        L.check(L.lib().seld_hc_conv_fwd_ex(ctypes.byref(desc), L.ptr(x), L.ptr_array8(ws), L.ptr(bias), L.ptr(y),
+                                            ctypes.c_int32(epilogue), L.ptr(_req(addend, "addend")), L.ptr(stats),
+                                            L.current_stream()), "seld_hc_conv_fwd")
     return y
 
 
@@ -75,8 +144,9 @@ def conv_bwd_data(desc, dy, ws, x_shape):
     dy = _req(dy, "dy")
     ws = [_req(w, "w") for w in ws]
     dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
-    L.check(L.lib().seld_hc_conv_bwd_data(ctypes.byref(desc), L.ptr(dy), L.ptr_array8(ws), L.ptr(dx),
-                                          L.current_stream()), "seld_hc_conv_bwd_data")
+    with _Timed(desc, 1):
+        L.check(L.lib().seld_hc_conv_bwd_data(ctypes.byref(desc), L.ptr(dy), L.ptr_array8(ws), L.ptr(dx),
+                                              L.current_stream()), "seld_hc_conv_bwd_data")
     return dx
 
 
@@ -87,9 +157,10 @@ def conv_bwd_weight(desc, x, dy, w_shape, want_bias):
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     dws = [torch.empty(w_shape, device=x.device, dtype=torch.float32) for _ in range(desc.algebra)]
     dbias = torch.empty(desc.Cout, device=x.device, dtype=torch.float32) if want_bias else None
-    L.check(L.lib().seld_hc_conv_bwd_weight(ctypes.byref(desc), L.ptr(x), L.ptr(dy), L.ptr_array8(dws), L.ptr(dbias),
-                                            L.ptr(ws), ctypes.c_size_t(nbytes), L.current_stream()),
-            "seld_hc_conv_bwd_weight")
+    with _Timed(desc, 2):
+        L.check(L.lib().seld_hc_conv_bwd_weight(ctypes.byref(desc), L.ptr(x), L.ptr(dy), L.ptr_array8(dws), L.ptr(dbias),
+                                                L.ptr(ws), ctypes.c_size_t(nbytes), L.current_stream()),
+                "seld_hc_conv_bwd_weight")
     return dws, dbias
 
 
