@@ -71,13 +71,27 @@ int seld_hc_conv_fwd_ex(const seld_conv_desc* d, const float* x, const float* co
 /* dx = conv_transpose(dy, W)   (autograd of the F.convNd call at quaternion_ops.py:147) */
 int seld_hc_conv_bwd_data(const seld_conv_desc* d, const float* dy, const float* const w[8],
                           float* dx, void* stream);
+/* Same with a caller-provided workspace of seld_hc_conv_bwd_data_workspace(d) bytes: the component tensors
+ * are transposed into it ([c][o][k], one tiny launch) so that the data gradient stages its weight rows
+ * with 16-byte loads exactly like the forward (about 2x faster on the TCN layers).  Without (or with too
+ * small) a workspace the gather path of seld_hc_conv_bwd_data is used. */
+size_t seld_hc_conv_bwd_data_workspace(const seld_conv_desc* d);
+int seld_hc_conv_bwd_data_ex(const seld_conv_desc* d, const float* dy, const float* const w[8],
+                             float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dw[c] (component gradients, same shapes as w[c]) and dbias (nullable).  The Hamilton fold
- * (sum of the signed blocks that share a component) is done on device. */
+ * (sum of the signed blocks that share a component) is done on device with float atomics, so no
+ * workspace is needed any more: seld_hc_conv_bwd_weight_workspace returns 0 and `workspace` may be NULL
+ * (both kept for ABI stability). */
 size_t seld_hc_conv_bwd_weight_workspace(const seld_conv_desc* d);
 int seld_hc_conv_bwd_weight(const seld_conv_desc* d, const float* x, const float* dy,
                             float* const dw[8], float* dbias /* nullable */,
                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same, but ACCUMULATES: dw[c] += ..., dbias += ... .  Lets the caller point dw at slices of one flat
+ * gradient buffer (zeroed once per step) so that no per-tensor gradient add is ever launched. */
+int seld_hc_conv_bwd_weight_acc(const seld_conv_desc* d, const float* x, const float* dy,
+                                float* const dw[8], float* dbias /* nullable */, void* stream);
 
 /* Diagnostics: label of the kernel symbol a call would launch ("hc_conv_kernel<4, 4, 1, 3>"), so that
  * HIP-event timings taken by the caller can be matched with rocprofv3's per-kernel statistics.

@@ -1,0 +1,87 @@
+// Shared declarations of the hypercomplex convolution kernels (hc_conv_fwd.hip, hc_wgrad.hip).
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+#include "common.h"
+
+namespace seld {
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct ConvP {
+    int algebra, mode;
+    int Csrc, Cdst;            // channels of the streamed operand / of the result
+    int srcH, srcW, dstH, dstW;
+    int KH, KW;
+    int SMh, OFFh, KDh, SDh;   // src index = d*SM + OFF + k*KD, then (if SD > 1) must divide by SD
+    int SMw, OFFw, KDw, SDw;
+    int Ktot;                  // Csrc * KH * KW
+    int OA, IA;                // Cout/A, Cin/A of the convolution
+    int srcS, dstS;
+    long long Ptot;            // N * dstS
+    long long src_elems;       // N * Csrc * srcS
+    int wt;                    // dgrad: component tensors are transposed to [c][o][k]
+    int skip_mode;             // 0 none, 1 (fwd DQ): low-half channels x high-half K is zero, 2 (dgrad DQ): high x low
+    int epilogue;
+    WPtrs w;
+    const float* src;
+    const float* bias;
+    float* dst;
+    const float* addend;
+    float* stats;
+};
+
+struct WgradP {
+    int algebra;
+    int N, Cin, Cout;
+    int inH, inW, outH, outW;
+    int KH, KW;
+    int sh, sw, ph, pw, dh, dw;
+    int Ktot;          // Cin*KK  (columns)
+    int OA, IA;
+    int inS, outS;
+    long long Ptot;    // N*outS  (reduction length)
+    int nsplit;
+    long long split_len;   // positions per split (multiple of 16)
+    const float* x;
+    const float* dy;
+    WPtrsMut gw;       // component gradients (accumulated into)
+};
+
+// Block (p, q) of the Hamilton matrix with one index per lane and the other wave-uniform:
+// returns the component, *zero for the structural zero quadrant, *neg for a negative sign.
+__device__ __forceinline__ int hc_comp(int algebra, int pp, int qq, bool* zero, bool* neg) {
+    *zero = false;
+    *neg = false;
+    if (algebra == 1) return 0;
+    *neg = (0x284Eu >> (((pp & 3) << 2) | (qq & 3))) & 1u;
+    int c = (pp ^ qq) & 3;
+    if (algebra == 8) {
+        const int hp = pp >> 2, hq = qq >> 2;
+        *zero = (hp == 0 && hq == 1);
+        if (hp == 1 && hq == 0) c += 4;
+    }
+    return c;
+}
+
+inline int hc_validate(const seld_conv_desc* d) {
+    if (!d) return SELD_EINVAL;
+    if (d->algebra != 1 && d->algebra != 4 && d->algebra != 8) return SELD_EINVAL;
+    if (d->ndim != 1 && d->ndim != 2) return SELD_EINVAL;
+    if (d->groups != 1) return SELD_EUNSUPPORTED;
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return SELD_EINVAL;
+    if (d->Cin % d->algebra || d->Cout % d->algebra) return SELD_EINVAL;
+    for (int i = 0; i < 2; ++i)
+        if (d->in[i] <= 0 || d->k[i] <= 0 || d->stride[i] <= 0 || d->dil[i] <= 0 || d->pad[i] < 0) return SELD_EINVAL;
+    if (d->k[0] * d->k[1] > 255) return SELD_EUNSUPPORTED;
+    // one image of either operand is addressed with 32-bit byte offsets
+    if ((long long)d->Cin * d->in[0] * d->in[1] >= (1LL << 28)) return SELD_EUNSUPPORTED;
+    return SELD_OK;
+}
+
+inline void hc_out_shape(const seld_conv_desc* d, int out[2]) {
+    for (int i = 0; i < 2; ++i)
+        out[i] = (d->in[i] + 2 * d->pad[i] - d->dil[i] * (d->k[i] - 1) - 1) / d->stride[i] + 1;
+}
+
+}  // namespace seld

@@ -1,0 +1,342 @@
+// Hypercomplex convolution, weight gradient, gfx950.
+//
+//   dWfull[co][ci*KK + kidx] = sum_{img,pos} dy[img][co][pos] * x[img][ci][src(pos, kidx)]
+//
+// One implicit GEMM on the fp32 MFMA with the reduction over positions, split over workgroups.  Each
+// workgroup folds its tile straight into the COMPONENT gradients with float atomics (sign applied), i.e.
+// the transpose of the assembly at quaternion_ops.py:131-135 -- no expanded gradient, no workspace, and
+// the tiles of the dual quaternion's structurally-zero quadrant are never computed.
+// The atomic payload is nsplit * 0.75 * Cout * Cin * K floats per call (a few MB: far below the
+// ~1.3 TB/s chip-wide float-atomic rate, guide Guideline 12).
+// Staging follows hc_conv_fwd.hip: wave w stages k-group w (4 consecutive positions) of every row, the
+// (image, row, column) of that group is tracked incrementally in SGPRs, per-row decodes are hoisted.
+#include "hc_common.h"
+
+namespace seld {
+
+template <int WRW /*waves along rows*/, int RT /*row tiles per wave*/, int CTL /*col tiles per wave*/, int KH_T, int KW_T>
+__global__ __launch_bounds__(256) void hc_wgrad_kernel(const WgradP p) {
+    constexpr int WCW = 4 / WRW;
+    constexpr int BM = WRW * RT * 16;
+    constexpr int BN = WCW * CTL * 16;
+    constexpr int AR = (BM + 63) / 64;
+    constexpr int BR = (BN + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float As[2][4][BM][4];   // dy   [k-group][co][4 positions]
+    __shared__ __attribute__((aligned(16))) float Bs[2][4][BN][4];   // xcol [k-group][col][4 positions]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr_ = wave / WCW, wc_ = wave % WCW;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int split = blockIdx.z;
+    const int KH = KH_T ? KH_T : p.KH;
+    const int KW = KW_T ? KW_T : p.KW;
+    const int KK = KH * KW;
+    const int CK = p.IA * KK;
+
+    // structural zero block of the dual-quaternion matrix: rows primal (co < Cout/2), cols dual (ci >= Cin/2)
+    if (p.algebra == 8 && m0 + BM <= (p.Cout >> 1) && n0 >= (p.Ktot >> 1)) return;
+
+    const long long pbeg = (long long)split * p.split_len;
+    long long pend = pbeg + p.split_len;
+    if (pend > p.Ptot) pend = p.Ptot;
+    const int nchunks = pbeg < pend ? (int)((pend - pbeg + 15) >> 4) : 0;
+
+    // hoisted per-lane decodes
+    bool a_ok[AR];
+    int a_co[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        const int r = lane + 64 * j;
+        a_ok[j] = r < BM && (m0 + r) < p.Cout;
+        a_co[j] = a_ok[j] ? m0 + r : 0;
+    }
+    bool b_ok[BR];
+    int b_coff[BR], b_dh[BR], b_dw[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int c = lane + 64 * j;
+        const int kk = n0 + c;
+        b_ok[j] = c < BN && kk < p.Ktot;
+        const int kkc = b_ok[j] ? kk : 0;
+        const int ci = kkc / KK;
+        const int kidx = kkc - ci * KK;
+        const int kh = kidx / KW, kw = kidx - kh * KW;
+        b_coff[j] = ci * p.inS;
+        b_dh[j] = kh * p.dh - p.ph;
+        b_dw[j] = kw * p.dw - p.pw;
+    }
+
+    // scalar tracker of this wave's first position  pbeg + 16*chunk + 4*wave = (img, oh, ow)
+    long long t_img;
+    int t_oh, t_ow;
+    {
+        const long long pos = pbeg + wave * 4;
+        t_img = pos / p.outS;
+        const int rem = (int)(pos - t_img * p.outS);
+        t_oh = rem / p.outW;
+        t_ow = rem - t_oh * p.outW;
+    }
+    const bool a_vec = (p.outS & 3) == 0;
+
+    float ar[AR][4], br[BR][4];
+
+    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+        const long long pos0 = pbeg + (long long)chunk * 16 + wave * 4;
+        // the 4 positions of this wave's group, as (img, oh, ow) in scalar registers
+        long long im[4];
+        int oh[4], ow[4];
+        {
+            long long i = t_img;
+            int h = t_oh, w = t_ow;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                im[s] = i; oh[s] = h; ow[s] = w;
+                if (++w >= p.outW) { w = 0; if (++h >= p.outH) { h = 0; ++i; } }
+            }
+        }
+        if (a_vec) {
+            const bool pin = pos0 < pend;        // outS % 4 == 0: the four positions share validity and image
+            const size_t base = (size_t)im[0] * p.Cout * p.outS + (size_t)oh[0] * p.outW + ow[0];
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pin && a_ok[j]) v = *reinterpret_cast<const float4*>(p.dy + base + (size_t)a_co[j] * p.outS);
+                ar[j][0] = v.x; ar[j][1] = v.y; ar[j][2] = v.z; ar[j][3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool pin = (pos0 + s) < pend;
+                const size_t base = (size_t)im[s] * p.Cout * p.outS + (size_t)oh[s] * p.outW + ow[s];
+#pragma unroll
+                for (int j = 0; j < AR; ++j) ar[j][s] = (pin && a_ok[j]) ? p.dy[base + (size_t)a_co[j] * p.outS] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool pin = (pos0 + s) < pend;
+            const float* xb = p.x + (size_t)im[s] * p.Cin * p.inS;
+            const int hh = oh[s] * p.sh, ww = ow[s] * p.sw;
+#pragma unroll
+            for (int j = 0; j < BR; ++j) {
+                const int ih = hh + b_dh[j], iw = ww + b_dw[j];
+                float v = 0.f;
+                if (pin && b_ok[j] && (unsigned)ih < (unsigned)p.inH && (unsigned)iw < (unsigned)p.inW)
+                    v = xb[b_coff[j] + ih * p.inW + iw];
+                br[j][s] = v;
+            }
+        }
+        // advance the tracker by 16 positions
+        t_ow += 16;
+        while (t_ow >= p.outW) {
+            t_ow -= p.outW;
+            if (++t_oh >= p.outH) { t_oh = 0; ++t_img; }
+        }
+    };
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            const int r = lane + 64 * j;
+            if (r < BM) *reinterpret_cast<float4*>(&As[buf][wave][r][0]) = make_float4(ar[j][0], ar[j][1], ar[j][2], ar[j][3]);
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int c = lane + 64 * j;
+            if (c < BN) *reinterpret_cast<float4*>(&Bs[buf][wave][c][0]) = make_float4(br[j][0], br[j][1], br[j][2], br[j][3]);
+        }
+    };
+
+    floatx4 acc[RT][CTL];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CTL; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fk = lane >> 4;
+    if (nchunks > 0) { load_chunk(0); store_chunk(0); }
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+        float av[RT][4], bv[CTL][4];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(&As[buf][fk][wr_ * (RT * 16) + i * 16 + fr][0]);
+            av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < CTL; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(&Bs[buf][fk][wc_ * (CTL * 16) + j * 16 + fr][0]);
+            bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+        if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    // D layout: col = lane&15 (B index = column kk), row = (lane>>4)*4 + r (A index = co).
+    // Fold into the component gradients: block (p, q) -> sign * dw[comp][o][c*KK + kidx].
+#pragma unroll
+    for (int j = 0; j < CTL; ++j) {
+        const int kk = n0 + wc_ * (CTL * 16) + j * 16 + fr;
+        if (kk >= p.Ktot) continue;
+        const int qq = kk / CK;
+        const int ckl = kk - qq * CK;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m0 + wr_ * (RT * 16) + i * 16 + fk * 4 + r;
+                if (co >= p.Cout) continue;
+                const int pp = co / p.OA;
+                const int o = co - pp * p.OA;
+                bool zero, neg;
+                const int comp = hc_comp(p.algebra, pp, qq, &zero, &neg);
+                if (zero) continue;
+                const float v = acc[i][j][r];
+                atomicAdd(p.gw.p[comp] + (size_t)o * CK + ckl, neg ? -v : v);
+            }
+        }
+    }
+}
+
+// per-channel sum over (N, S): dbias  (accumulates)
+__global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, int S, float* __restrict__ out) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    const long long total = (long long)N * S;
+    for (long long i = threadIdx.x; i < total; i += blockDim.x) {
+        long long n = i / S;
+        int r = (int)(i - n * S);
+        s += x[((size_t)n * C + c) * S + r];
+    }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] += red[0] + red[1] + red[2] + red[3];
+}
+
+struct ZeroP {
+    float* p[9];
+    long long n[9];
+};
+__global__ void zero_many_kernel(const ZeroP z) {
+    float* dst = z.p[blockIdx.y];
+    const long long n = z.n[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = 0.f;
+}
+
+static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, long long* split_len) {
+    long long Ptot = (long long)d->N * o[0] * o[1];
+    long long Ktot = (long long)d->Cin * d->k[0] * d->k[1];
+    long long tiles = ((d->Cout + bm - 1) / bm) * ((Ktot + bn - 1) / bn);
+    if (d->algebra == 8) tiles = tiles * 3 / 4 > 0 ? tiles * 3 / 4 : 1;   // zero-quadrant tiles exit at once
+    long long want = (768 + tiles - 1) / tiles;           // ~3 workgroups per CU
+    long long maxs = (Ptot + 511) / 512;                  // at least 512 positions per split
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    long long len = (Ptot + want - 1) / want;
+    len = (len + 15) / 16 * 16;
+    int ns = (int)((Ptot + len - 1) / len);
+    *split_len = len;
+    return ns < 1 ? 1 : ns;
+}
+
+// tile configuration: 0 = 128 x 128 (waves 2 x 2), 1 = 192 x 80 for short K (first layer), 2 = 64 x 64 (small layers)
+static int wgrad_cfg(const seld_conv_desc* d) {
+    const int Ktot = d->Cin * d->k[0] * d->k[1];
+    if (Ktot <= 80 && d->Cout > 64) return 1;
+    if (d->Cout <= 64 || Ktot <= 64) return 2;
+    return 0;
+}
+
+template <int WRW, int RT, int CTL>
+static void launch_wgrad(const WgradP& p, hipStream_t st) {
+    constexpr int BM = WRW * RT * 16, BN = (4 / WRW) * CTL * 16;
+    dim3 grid((p.Ktot + BN - 1) / BN, (p.Cout + BM - 1) / BM, p.nsplit);
+    if (p.KH == 1 && p.KW == 1) hipLaunchKernelGGL((hc_wgrad_kernel<WRW, RT, CTL, 1, 1>), grid, dim3(256), 0, st, p);
+    else if (p.KH == 1 && p.KW == 3) hipLaunchKernelGGL((hc_wgrad_kernel<WRW, RT, CTL, 1, 3>), grid, dim3(256), 0, st, p);
+    else if (p.KH == 3 && p.KW == 3) hipLaunchKernelGGL((hc_wgrad_kernel<WRW, RT, CTL, 3, 3>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((hc_wgrad_kernel<WRW, RT, CTL, 0, 0>), grid, dim3(256), 0, st, p);
+}
+
+static int wgrad_run(const seld_conv_desc* d, const float* x, const float* dy, float* const dw[8], float* dbias,
+                     int accumulate, hipStream_t st) {
+    int rc = hc_validate(d);
+    if (rc) return rc;
+    int o[2];
+    hc_out_shape(d, o);
+    if (o[0] <= 0 || o[1] <= 0 || !x || !dy || !dw) return SELD_EINVAL;
+    WgradP p{};
+    p.algebra = d->algebra; p.N = d->N; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.inH = d->in[0]; p.inW = d->in[1]; p.outH = o[0]; p.outW = o[1];
+    p.KH = d->k[0]; p.KW = d->k[1];
+    p.sh = d->stride[0]; p.sw = d->stride[1]; p.ph = d->pad[0]; p.pw = d->pad[1]; p.dh = d->dil[0]; p.dw = d->dil[1];
+    p.Ktot = d->Cin * p.KH * p.KW;
+    p.OA = d->Cout / d->algebra; p.IA = d->Cin / d->algebra;
+    p.inS = p.inH * p.inW; p.outS = p.outH * p.outW;
+    p.Ptot = (long long)d->N * p.outS;
+    p.x = x; p.dy = dy;
+    for (int i = 0; i < 8; ++i) p.gw.p[i] = (i < d->algebra) ? dw[i] : nullptr;
+    if (!accumulate) {
+        ZeroP z{};
+        const long long per = (long long)p.OA * p.IA * p.KH * p.KW;
+        int n = 0;
+        for (int i = 0; i < d->algebra; ++i) { z.p[n] = dw[i]; z.n[n] = per; ++n; }
+        if (dbias) { z.p[n] = dbias; z.n[n] = d->Cout; ++n; }
+        const long long blocks = (per + 255) / 256;
+        hipLaunchKernelGGL(zero_many_kernel, dim3((unsigned)(blocks > 64 ? 64 : blocks), n), dim3(256), 0, st, z);
+        rc = check_launch();
+        if (rc) return rc;
+    }
+    const int cfg = wgrad_cfg(d);
+    if (cfg == 0) { p.nsplit = wgrad_splits(d, o, 128, 128, &p.split_len); launch_wgrad<2, 4, 4>(p, st); }
+    else if (cfg == 1) { p.nsplit = wgrad_splits(d, o, 192, 80, &p.split_len); launch_wgrad<4, 3, 5>(p, st); }
+    else { p.nsplit = wgrad_splits(d, o, 64, 64, &p.split_len); launch_wgrad<2, 2, 2>(p, st); }
+    rc = check_launch();
+    if (rc) return rc;
+    if (dbias) {
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(d->Cout), dim3(256), 0, st, dy, d->N, d->Cout, p.outS, dbias);
+        rc = check_launch();
+    }
+    return rc;
+}
+
+int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
+    int kh = d->k[0], kw = d->k[1];
+    if (!((kh == 1 && kw == 1) || (kh == 1 && kw == 3) || (kh == 3 && kw == 3))) kh = kw = 0;
+    const int cfg = wgrad_cfg(d);
+    const char* t = cfg == 0 ? "2, 4, 4" : (cfg == 1 ? "4, 3, 5" : "2, 2, 2");
+    snprintf(buf, buflen, "hc_wgrad_kernel<%s, %d, %d>", t, kh, kw);
+    return SELD_OK;
+}
+
+}  // namespace seld
+using namespace seld;
+
+extern "C" size_t seld_hc_conv_bwd_weight_workspace(const seld_conv_desc* d) {
+    (void)d;
+    return 0;      // the fold is done with atomics; kept for ABI stability
+}
+
+extern "C" int seld_hc_conv_bwd_weight(const seld_conv_desc* d, const float* x, const float* dy,
+                                       float* const dw[8], float* dbias, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    return wgrad_run(d, x, dy, dw, dbias, 0, (hipStream_t)stream);
+}
+
+// dw[c] += ..., dbias += ...  (gradient accumulation straight into the optimiser's flat gradient buffer)
+extern "C" int seld_hc_conv_bwd_weight_acc(const seld_conv_desc* d, const float* x, const float* dy,
+                                           float* const dw[8], float* dbias, void* stream) {
+    return wgrad_run(d, x, dy, dw, dbias, 1, (hipStream_t)stream);
+}

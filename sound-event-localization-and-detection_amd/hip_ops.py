@@ -144,24 +144,58 @@ def conv_bwd_data(desc, dy, ws, x_shape):
     dy = _req(dy, "dy")
     ws = [_req(w, "w") for w in ws]
     dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    lib = L.lib()
+    lib.seld_hc_conv_bwd_data_workspace.restype = ctypes.c_size_t
+    nbytes = lib.seld_hc_conv_bwd_data_workspace(ctypes.byref(desc))
+    wsb = torch.empty((nbytes + 3) // 4, device=dy.device, dtype=torch.float32)
     with _Timed(desc, 1):
-        L.check(L.lib().seld_hc_conv_bwd_data(ctypes.byref(desc), L.ptr(dy), L.ptr_array8(ws), L.ptr(dx),
-                                              L.current_stream()), "seld_hc_conv_bwd_data")
+        L.check(lib.seld_hc_conv_bwd_data_ex(ctypes.byref(desc), L.ptr(dy), L.ptr_array8(ws), L.ptr(dx), L.ptr(wsb),
+                                             ctypes.c_size_t(nbytes), L.current_stream()), "seld_hc_conv_bwd_data")
     return dx
 
 
-def conv_bwd_weight(desc, x, dy, w_shape, want_bias):
+def conv_bwd_weight(desc, x, dy, w_shape, want_bias, into=None, bias_into=None):
+    """Component weight gradients.  `into` (list of A tensors, e.g. views of FlatAdam.flat_grad) selects the
+    accumulating entry point: the kernel adds straight into them and nothing is returned for autograd."""
     x = _req(x, "x")
     dy = _req(dy, "dy")
-    nbytes = L.lib().seld_hc_conv_bwd_weight_workspace(ctypes.byref(desc))
-    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    if into is not None:
+        with _Timed(desc, 2):
+            L.check(L.lib().seld_hc_conv_bwd_weight_acc(ctypes.byref(desc), L.ptr(x), L.ptr(dy), L.ptr_array8(into),
+                                                        L.ptr(bias_into), L.current_stream()),
+                    "seld_hc_conv_bwd_weight_acc")
+        return None, None
     dws = [torch.empty(w_shape, device=x.device, dtype=torch.float32) for _ in range(desc.algebra)]
     dbias = torch.empty(desc.Cout, device=x.device, dtype=torch.float32) if want_bias else None
     with _Timed(desc, 2):
         L.check(L.lib().seld_hc_conv_bwd_weight(ctypes.byref(desc), L.ptr(x), L.ptr(dy), L.ptr_array8(dws), L.ptr(dbias),
-                                                L.ptr(ws), ctypes.c_size_t(nbytes), L.current_stream()),
+                                                None, ctypes.c_size_t(0), L.current_stream()),
                 "seld_hc_conv_bwd_weight")
     return dws, dbias
+
+
+def _direct_targets(params, bias):
+    """Gradient slots to accumulate into directly, or None.  A parameter opts in when its owner (FlatAdam)
+    pre-attached `.grad` as a view of a flat buffer and set `_seld_direct_grad`."""
+    ts = list(params) + ([bias] if bias is not None else [])
+    if all(getattr(t, "_seld_direct_grad", False) and t.grad is not None for t in ts):
+        return [t.grad for t in params], (bias.grad if bias is not None else None)
+    return None
+
+
+def _conv_backward(ctx, dy, first_w):
+    x = ctx.saved_tensors[0]
+    ws = ctx.w_params
+    dy = _req(dy, "dy")
+    dx = conv_bwd_data(ctx.desc, dy, ws, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+    dws, dbias = [None] * len(ws), None
+    if any(ctx.needs_input_grad[first_w:]) or (ctx.has_bias and ctx.needs_input_grad[1]):
+        direct = _direct_targets(ws, ctx.bias_param)
+        if direct is not None:
+            conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias, into=direct[0], bias_into=direct[1])
+        else:
+            dws, dbias = conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias)
+    return dx, dbias, dws
 
 
 class HyperConvFn(torch.autograd.Function):
@@ -176,20 +210,13 @@ class HyperConvFn(torch.autograd.Function):
         y = conv_fwd(desc, x, ws, bias)
         ctx.desc = desc
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, *ws)
+        ctx.w_params, ctx.bias_param = ws, bias
+        ctx.save_for_backward(x)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, *ws = ctx.saved_tensors
-        dy = _req(dy, "dy")
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = conv_bwd_data(ctx.desc, dy, ws, tuple(x.shape))
-        dws = [None] * len(ws)
-        dbias = None
-        if any(ctx.needs_input_grad[5:]) or (ctx.has_bias and ctx.needs_input_grad[1]):
-            dws, dbias = conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias)
+        dx, dbias, dws = _conv_backward(ctx, dy, 5)
         return (dx, dbias, None, None, None, *dws)
 
 
@@ -213,17 +240,13 @@ class HyperConvAddFn(torch.autograd.Function):
         y = conv_fwd(desc, x, ws, bias, epilogue=L.SELD_EPI_ADD, addend=addend)
         ctx.desc = desc
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, *ws)
+        ctx.w_params, ctx.bias_param = ws, bias
+        ctx.save_for_backward(x)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, *ws = ctx.saved_tensors
-        dy = _req(dy, "dy")
-        dx = conv_bwd_data(ctx.desc, dy, ws, tuple(x.shape)) if ctx.needs_input_grad[0] else None
-        dws, dbias = [None] * len(ws), None
-        if any(ctx.needs_input_grad[6:]) or (ctx.has_bias and ctx.needs_input_grad[1]):
-            dws, dbias = conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias)
+        dx, dbias, dws = _conv_backward(ctx, dy, 6)
         return (dx, dbias, dy if ctx.needs_input_grad[2] else None, None, None, None, *dws)
 
 

@@ -81,6 +81,7 @@ class FlatAdam:
                 self.flat_param[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[off:off + n].view(p.shape)
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
+                p._seld_direct_grad = True      # HIP backward kernels accumulate straight into this view
                 off += n
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=self.params)]
         self.step_count = 0
