@@ -55,8 +55,13 @@ typedef struct seld_conv_desc {
 #define SELD_EPI_NONE        0
 #define SELD_EPI_ACCUMULATE  1   /* y += conv(x)   (skip-connection running sum, model.py:210-212) */
 #define SELD_EPI_ADD         2   /* y = conv(x) + addend  (x + conv2_residual(y), model.py:132)    */
-#define SELD_EPI_STATS       4   /* also atomically accumulate per-channel sum / sum-of-squares
-                                    of the stored result into stats[0:Cout] / stats[Cout:2*Cout] */
+#define SELD_EPI_STATS       4   /* also accumulate the per-channel sum / sum of squares of the stored result
+                                    (BatchNorm batch statistics) into a stats buffer, see below            */
+
+/* Layout of every `stats` buffer: SELD_STATS_REPLICAS rows of 2*C floats [sum(C) | sum of squares(C)];
+ * producers add to row (workgroup index % replicas) so that thousands of workgroups do not serialise on
+ * 2*C addresses; seld_bn_finalize sums the rows.  The caller zero-fills the buffer before use. */
+#define SELD_STATS_REPLICAS 64
 
 int seld_hc_conv_out_shape(const seld_conv_desc* d, int32_t out[2]);
 
@@ -129,7 +134,7 @@ int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_features, int32_t 
 #define SELD_ACT_TANH    2
 #define SELD_ACT_SIGMOID 3
 
-/* stats[0:C] = sum, stats[C:2C] = sum of squares (accumulated atomically; caller pre-zeroes) */
+/* per-channel sum / sum of squares of x (N, C, S) into a stats buffer (layout above) */
 int seld_channel_stats(const float* x, int32_t N, int32_t C, int32_t S, float* stats, void* stream);
 
 /* from raw sums: mean/invstd (saved for backward) and the running-stat update (train mode) */
@@ -140,6 +145,18 @@ int seld_bn_finalize(const float* stats, int32_t C, int64_t count, float eps, fl
 /* eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps) */
 int seld_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
                        float* mean, float* invstd, void* stream);
+
+/* BatchNorm2d -> ReLU -> MaxPool2d(ph, pw) (stride = window, floor mode) in one pass (model.py:278-281):
+ * reads the conv output y (N, C, H, W), writes the pooled map and a uint8 arg-max per pooled element. */
+int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                          const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          float* pooled, uint8_t* idx, void* stream);
+/* Backward of the above: red (2C, pre-zeroed) receives dgamma | dbeta (reduced from pooled-size tensors
+ * only), dy (N, C, H, W) the gradient w.r.t. the conv output.  train = 0: running statistics were used. */
+int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                          int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
+                          const float* invstd, const float* gamma, const float* beta, int32_t train,
+                          float* red, float* dy, void* stream);
 
 /* y = act(gamma * (x - mean) * invstd + beta) */
 int seld_bn_act_fwd(const float* x, int32_t N, int32_t C, int32_t S, const float* mean, const float* invstd,
@@ -196,6 +213,7 @@ int seld_dropout_mask_rows(int64_t rows, float p, uint64_t seed, uint64_t offset
 
 /* y = a + b ; y += b */
 int seld_add(const float* a, const float* b, int64_t n, float* y, void* stream);
+int seld_accumulate(float* dst, const float* src, int64_t n, void* stream);   /* dst += src */
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head self attention core (model.py:39-48): out = softmax(q k^T / sqrt(hd)) v, flash style

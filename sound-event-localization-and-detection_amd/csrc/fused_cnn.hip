@@ -1,0 +1,189 @@
+// Fused CNN-stage tail for gfx950:  BatchNorm2d -> ReLU -> MaxPool2d(ph, pw)   (model.py:278-281)
+//
+// The reference runs these as three full-resolution passes forward and three backward; on the first
+// stage the map is 1.6 GB at batch 32, so they dominate the HBM traffic of a training step.  Here:
+//   forward : ONE pass reads the conv output y and writes only the pooled map (1/ph/pw of the size)
+//             plus a uint8 argmax per pooled element;
+//   backward: the per-channel reductions need only pooled-size tensors, because at an arg-max with
+//             z = relu(gamma * xhat + beta) > 0 the normalised input is xhat = (z - beta) / gamma and
+//             every other position of the window has dz = 0; ONE full-resolution pass then writes the
+//             gradient w.r.t. the conv output.
+// The BatchNorm batch statistics themselves come from the convolution's epilogue (SELD_EPI_STATS).
+#include "common.h"
+
+namespace seld {
+
+struct PoolGeom {
+    long long NC;
+    int C, H, W, ph, pw, OH, OW;
+};
+
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, PoolGeom g,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               float* __restrict__ pooled, uint8_t* __restrict__ idx) {
+    const long long total = g.NC * g.OH * g.OW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ow = (int)(i % g.OW);
+        const long long t = i / g.OW;
+        const int oh = (int)(t % g.OH);
+        const long long nc = t / g.OH;
+        const int c = (int)(nc % g.C);
+        const float a = gamma[c] * invstd[c];
+        const float b = beta[c] - mean[c] * a;
+        const float* base = y + ((size_t)nc * g.H + (size_t)oh * g.ph) * g.W + (size_t)ow * g.pw;
+        float best = 0.f;
+        int bi = 0;
+        for (int r = 0; r < g.ph; ++r)
+            for (int s = 0; s < g.pw; ++s) {
+                float z = base[(size_t)r * g.W + s] * a + b;
+                z = z > 0.f ? z : 0.f;
+                if ((r | s) == 0 || z > best || z != z) { best = z; bi = r * g.pw + s; }
+            }
+        pooled[i] = best;
+        idx[i] = (uint8_t)bi;
+    }
+}
+
+// red[c] += sum dz * xhat, red[C + c] += sum dz   over the pooled elements of channel c
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const float* __restrict__ dpooled,
+                                                                      const float* __restrict__ pooled, int N, int C,
+                                                                      int S /* OH*OW */, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta,
+                                                                      const float* __restrict__ y,
+                                                                      const uint8_t* __restrict__ idx, PoolGeom g,
+                                                                      const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd,
+                                                                      float* __restrict__ red) {
+    const int c = blockIdx.y;
+    const bool degenerate = gamma[c] == 0.f;      // xhat cannot be recovered from z: gather it from y instead
+    const float inv_g = degenerate ? 0.f : 1.0f / gamma[c];
+    const float be = beta[c];
+    const long long M = (long long)N * S;
+    const long long beg = (long long)blockIdx.x * 8192;
+    long long end = beg + 8192;
+    if (end > M) end = M;
+    float v0 = 0.f, v1 = 0.f;
+    for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        const long long n = i / S;
+        const size_t off = ((size_t)n * C + c) * S + (size_t)(i - n * S);
+        const float z = pooled[off];
+        if (z > 0.f) {
+            const float d = dpooled[off];
+            float xh = (z - be) * inv_g;
+            if (degenerate) {
+                const int s_ = (int)(i - n * S);
+                const int oh = s_ / g.OW, ow = s_ - oh * g.OW;
+                const int am = idx[off];
+                const int r = am / g.pw, q = am - r * g.pw;
+                xh = (y[(((size_t)n * C + c) * g.H + (size_t)oh * g.ph + r) * g.W + (size_t)ow * g.pw + q] - mean[c]) * invstd[c];
+            }
+            v0 += d * xh;
+            v1 += d;
+        }
+    }
+    __shared__ float r0[4], r1[4];
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = v0; r1[threadIdx.x >> 6] = v1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(red + c, r0[0] + r0[1] + r0[2] + r0[3]);
+        atomicAdd(red + C + c, r1[0] + r1[1] + r1[2] + r1[3]);
+    }
+}
+
+// dy[n,c,h,w] = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)),  dz = dpooled at the arg-max with z > 0
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_kernel(const float* __restrict__ dpooled,
+                                                                     const float* __restrict__ pooled,
+                                                                     const uint8_t* __restrict__ idx,
+                                                                     const float* __restrict__ y, PoolGeom g,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ red, float inv_count,
+                                                                     int train, float* __restrict__ dy) {
+    // one thread per (nc, oh', ow') where oh' also covers the rows that floor-mode pooling drops
+    const int OHx = (g.H + g.ph - 1) / g.ph, OWx = (g.W + g.pw - 1) / g.pw;
+    const long long total = g.NC * OHx * OWx;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ow = (int)(i % OWx);
+        const long long t = i / OWx;
+        const int oh = (int)(t % OHx);
+        const long long nc = t / OHx;
+        const int c = (int)(nc % g.C);
+        const float mu = mean[c], is = invstd[c];
+        const float a = gamma[c] * is;
+        const float k1 = train ? red[g.C + c] * inv_count : 0.f;
+        const float k2 = train ? red[c] * inv_count : 0.f;
+        float dz = 0.f;
+        int am = -1;
+        if (oh < g.OH && ow < g.OW) {
+            const size_t o = ((size_t)nc * g.OH + oh) * g.OW + ow;
+            if (pooled[o] > 0.f) { dz = dpooled[o]; am = idx[o]; }
+        }
+        for (int r = 0; r < g.ph; ++r) {
+            const int h = oh * g.ph + r;
+            if (h >= g.H) break;
+            for (int s = 0; s < g.pw; ++s) {
+                const int w = ow * g.pw + s;
+                if (w >= g.W) break;
+                const size_t off = ((size_t)nc * g.H + h) * g.W + w;
+                const float xh = (y[off] - mu) * is;
+                const float d = (r * g.pw + s == am) ? dz : 0.f;
+                dy[off] = a * (d - k1 - xh * k2);
+            }
+        }
+    }
+}
+
+static inline unsigned grid_cap(long long items) {
+    long long b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 16384) b = 16384;
+    return (unsigned)b;
+}
+
+}  // namespace seld
+using namespace seld;
+
+static int mk_geom(PoolGeom& g, int N, int C, int H, int W, int ph, int pw) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || ph * pw > 255 || H < ph || W < pw) return SELD_EINVAL;
+    g.NC = (long long)N * C; g.C = C; g.H = H; g.W = W; g.ph = ph; g.pw = pw; g.OH = H / ph; g.OW = W / pw;
+    return SELD_OK;
+}
+
+extern "C" int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                                     const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     float* pooled, uint8_t* idx, void* stream) {
+    PoolGeom g;
+    int rc = mk_geom(g, N, C, H, W, ph, pw);
+    if (rc) return rc;
+    if (!y || !mean || !invstd || !gamma || !beta || !pooled || !idx) return SELD_EINVAL;
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(grid_cap(g.NC * g.OH * g.OW)), dim3(256), 0, (hipStream_t)stream, y, g,
+                       mean, invstd, gamma, beta, pooled, idx);
+    return check_launch();
+}
+
+extern "C" int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                                     int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, int32_t train,
+                                     float* red /* (2C) pre-zeroed: dgamma | dbeta */, float* dy, void* stream) {
+    PoolGeom g;
+    int rc = mk_geom(g, N, C, H, W, ph, pw);
+    if (rc) return rc;
+    if (!dpooled || !pooled || !idx || !y || !mean || !invstd || !gamma || !beta || !red || !dy) return SELD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = g.OH * g.OW;
+    const long long M = (long long)N * S;
+    hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel, dim3((unsigned)((M + 8191) / 8192), C), dim3(256), 0, st, dpooled, pooled,
+                       N, C, S, gamma, beta, y, idx, g, mean, invstd, red);
+    rc = check_launch();
+    if (rc) return rc;
+    const int OHx = (H + ph - 1) / ph, OWx = (W + pw - 1) / pw;
+    hipLaunchKernelGGL(bn_relu_pool_bwd_apply_kernel, dim3(grid_cap(g.NC * OHx * OWx)), dim3(256), 0, st, dpooled, pooled, idx, y,
+                       g, mean, invstd, gamma, red, 1.0f / (float)((long long)N * H * W), train, dy);
+    return check_launch();
+}

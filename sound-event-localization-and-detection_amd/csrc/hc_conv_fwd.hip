@@ -400,14 +400,35 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
             }
         }
         if (p.epilogue & SELD_EPI_STATS) {
-            // lanes fr, fr+16, fr+32, fr+48 hold the same channel
+            // lanes fr, fr+16, fr+32, fr+48 hold the same channel; the 4 waves hold different positions
             s1 += __shfl_xor(s1, 16, 64);
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            if (fk == 0 && chok) {
-                atomicAdd(p.stats + ch, s1);
-                atomicAdd(p.stats + p.Cdst + ch, s2);
+            if (fk == 0) {
+                float* redbuf = &Xs[0][0][0][0];       // the K loop is over: the staging buffers are free
+                redbuf[(wave * BC + j * 16 + fr) * 2 + 0] = s1;
+                redbuf[(wave * BC + j * 16 + fr) * 2 + 1] = s2;
+            }
+        }
+    }
+    if (p.epilogue & SELD_EPI_STATS) {
+        // one atomic pair per channel per workgroup, spread over SELD_STATS_REPLICAS rows so that the
+        // thousands of workgroups of a layer do not serialise on 2*C addresses
+        __syncthreads();
+        const float* redbuf = &Xs[0][0][0][0];
+        float* rep = p.stats + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
+        for (int t = tid; t < BC; t += 256) {
+            const int ch = c0 + t;
+            if (ch < p.Cdst) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) {
+                    a1 += redbuf[(wv * BC + t) * 2 + 0];
+                    a2 += redbuf[(wv * BC + t) * 2 + 1];
+                }
+                atomicAdd(rep + ch, a1);
+                atomicAdd(rep + p.Cdst + ch, a2);
             }
         }
     }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const LinP p, int rows
 }
 
 // dM[i][o] = sum_r x[r][i] * dy[r][o]
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int in_f, int out_f, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int rows_per_split, int in_f, int out_f, const float* __restrict__ x,
                                                            const float* __restrict__ dy, float* __restrict__ dM) {
     __shared__ float Xs[16][64 + 4];
     __shared__ float Ds[16][64 + 4];
@@ -90,11 +90,14 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int in_f, i
     const int i0 = blockIdx.y * 64, o0 = blockIdx.x * 64;
     const int ti = (tid >> 4) * 4, to = (tid & 15) * 4;
     float acc[4][4] = {};
-    for (int r0 = 0; r0 < rows; r0 += 16) {
+    const int rbeg = blockIdx.z * rows_per_split;
+    int rend = rbeg + rows_per_split;
+    if (rend > rows) rend = rows;
+    for (int r0 = rbeg; r0 < rend; r0 += 16) {
         for (int e = tid; e < 64 * 16; e += 256) {
             const int c = e & 63, r = e >> 6;
-            Xs[r][c] = (r0 + r < rows && i0 + c < in_f) ? x[(size_t)(r0 + r) * in_f + i0 + c] : 0.f;
-            Ds[r][c] = (r0 + r < rows && o0 + c < out_f) ? dy[(size_t)(r0 + r) * out_f + o0 + c] : 0.f;
+            Xs[r][c] = (r0 + r < rend && i0 + c < in_f) ? x[(size_t)(r0 + r) * in_f + i0 + c] : 0.f;
+            Ds[r][c] = (r0 + r < rend && o0 + c < out_f) ? dy[(size_t)(r0 + r) * out_f + o0 + c] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int in_f, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ii = i0 + ti + i, oo = o0 + to + j;
-            if (ii < in_f && oo < out_f) dM[(size_t)ii * out_f + oo] = acc[i][j];
+            if (ii < in_f && oo < out_f) atomicAdd(dM + (size_t)ii * out_f + oo, acc[i][j]);
         }
 }
 
@@ -145,12 +148,20 @@ __global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, W
     dw.p[comp][rem] = total;
 }
 
-__global__ void column_sum_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ x, int rows, int cols,
+                                                         int rows_per_block, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(size_t)r * cols + c];
-    out[c] = s;
+    if (c < cols)
+        for (int r = r0 + ty; r < r1; r += 4) s += x[(size_t)r * cols + c];
+    red[ty][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ty == 0 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 static int mk_lin(LinP& p, int kind, int in_f, int out_f, const float* const w[8]) {
@@ -199,8 +210,10 @@ extern "C" int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_feature
     if (dw) {
         if (!x) return SELD_EINVAL;
         if (!workspace || workspace_bytes < seld_hc_linear_bwd_workspace(kind, in_features, out_features)) return SELD_EWORKSPACE;
-        dim3 grid((out_features + 63) / 64, (in_features + 63) / 64);
-        hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, st, rows, in_features, out_features, x, dy, (float*)workspace);
+        const int rps = 128;
+        dim3 grid((out_features + 63) / 64, (in_features + 63) / 64, (rows + rps - 1) / rps);
+        if (hipMemsetAsync(workspace, 0, (size_t)in_features * out_features * sizeof(float), st) != hipSuccess) return SELD_ELAUNCH;
+        hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, st, rows, rps, in_features, out_features, x, dy, (float*)workspace);
         rc = check_launch();
         if (rc) return rc;
         WPtrsMut out{};
@@ -211,7 +224,10 @@ extern "C" int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_feature
         if (rc) return rc;
     }
     if (dbias) {
-        hipLaunchKernelGGL(column_sum_kernel, dim3((out_features + 255) / 256), dim3(256), 0, st, dy, rows, out_features, dbias);
+        const int rpb = 64;
+        if (hipMemsetAsync(dbias, 0, (size_t)out_features * sizeof(float), st) != hipSuccess) return SELD_ELAUNCH;
+        hipLaunchKernelGGL(column_sum_kernel, dim3((out_features + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, st, dy, rows,
+                           out_features, rpb, dbias);
         rc = check_launch();
     }
     return rc;

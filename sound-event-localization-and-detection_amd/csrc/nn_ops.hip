@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
             v[1] += a * a;
         }
     });
-    float* const dst[2] = {stats + c, stats + C + c};
+    float* rep = stats + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * C;
+    float* const dst[2] = {rep + c, rep + C + c};
     block_atomic<2>(v, dst);
 }
 
@@ -90,8 +91,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, doubl
                                    float* __restrict__ rmean, float* __restrict__ rvar) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = (double)stats[c] / count;
-    double var = (double)stats[C + c] / count - m * m;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < SELD_STATS_REPLICAS; ++r) {
+        s1 += (double)stats[(size_t)r * 2 * C + c];
+        s2 += (double)stats[(size_t)r * 2 * C + C + c];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -603,6 +609,13 @@ extern "C" int seld_act_bwd(const float* dy, const float* y, int64_t n, int32_t 
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), dy, y, (long long)n, act, dx);
     return check_launch();
 }
+extern "C" int seld_accumulate(float* dst, const float* src, int64_t n, void* stream) {
+    if (!dst || !src || n < 0) return SELD_EINVAL;
+    if (n == 0) return SELD_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), (const float*)dst, src, (long long)n, dst);
+    return check_launch();
+}
+
 extern "C" int seld_add(const float* a, const float* b, int64_t n, float* y, void* stream) {
     if (!a || !b || !y || n < 0) return SELD_EINVAL;
     if (n == 0) return SELD_OK;

@@ -265,9 +265,17 @@ def _ncs(x):
     return N, C, S
 
 
+STATS_REPLICAS = 64      # SELD_STATS_REPLICAS
+
+
+def new_stats(C, device):
+    """Zeroed BatchNorm statistics buffer: SELD_STATS_REPLICAS rows of [sum(C) | sum of squares(C)]."""
+    return torch.zeros(STATS_REPLICAS * 2 * C, device=device, dtype=torch.float32)
+
+
 def channel_stats(x):
     N, C, S = _ncs(x)
-    stats = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    stats = new_stats(C, x.device)
     L.check(L.lib().seld_channel_stats(L.ptr(x), N, C, S, L.ptr(stats), L.current_stream()), "seld_channel_stats")
     return stats
 
@@ -692,3 +700,85 @@ def gate_plain(yf, yg, mask=None):
         weight, bias, running_mean, running_var = one, zero, zero, one
         training, momentum, eps, num_batches_tracked = False, 0.1, 0.0, None
     return GateFn.apply(yf, yg, one, zero, zero, one, one, zero, zero, one, False, 0.1, 0.0, mask)
+
+
+# ======================================================================================
+# fused CNN stage: conv (+ BatchNorm statistics in its epilogue) -> BN -> ReLU -> MaxPool
+# ======================================================================================
+class HyperConvStatsFn(torch.autograd.Function):
+    """y = W (x) x and, from the same kernel's epilogue, the per-channel sum / sum of squares of y
+    (SELD_EPI_STATS) that the BatchNorm which follows needs: saves one full read of y."""
+
+    @staticmethod
+    def forward(ctx, x, bias, stride, padding, dilation, *ws):
+        algebra = len(ws)
+        k = tuple(ws[0].shape[2:])
+        desc = make_conv_desc(tuple(x.shape), ws[0].shape[0] * algebra, algebra, k, stride, padding, dilation)
+        x = _req(x, "x")
+        stats = new_stats(desc.Cout, x.device)
+        y = conv_fwd(desc, x, ws, bias, epilogue=L.SELD_EPI_STATS, stats=stats)
+        ctx.desc = desc
+        ctx.has_bias = bias is not None
+        ctx.w_params, ctx.bias_param = ws, bias
+        ctx.save_for_backward(x)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        dx, dbias, dws = _conv_backward(ctx, dy, 5)
+        return (dx, dbias, None, None, None, *dws)
+
+
+def hyper_conv_stats(x, ws, bias, stride, padding, dilation):
+    return HyperConvStatsFn.apply(x, bias, stride, padding, dilation, *ws)
+
+
+class BnReluPoolFn(torch.autograd.Function):
+    """MaxPool2d(ph, pw)(ReLU(BatchNorm2d(y))) in one pass each way (model.py:278-281)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, ph, pw, stats):
+        y = _req(y, "y")
+        N, C, Hh, Ww = y.shape
+        mean, invstd = bn_prepare(y, running_mean, running_var, training, momentum, eps, stats)
+        pooled = torch.empty((N, C, Hh // ph, Ww // pw), device=y.device, dtype=torch.float32)
+        idx = torch.empty(pooled.shape, device=y.device, dtype=torch.uint8)
+        L.check(L.lib().seld_bn_relu_pool_fwd(L.ptr(y), N, C, Hh, Ww, ph, pw, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                              L.ptr(beta), L.ptr(pooled), L.ptr(idx), L.current_stream()),
+                "seld_bn_relu_pool_fwd")
+        ctx.geom = (N, C, Hh, Ww, ph, pw, training)
+        ctx.bn_params = (gamma, beta)
+        ctx.save_for_backward(y, pooled, idx, mean, invstd)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        y, pooled, idx, mean, invstd = ctx.saved_tensors
+        gamma, beta = ctx.bn_params
+        N, C, Hh, Ww, ph, pw, training = ctx.geom
+        dpooled = _req(dpooled, "dpooled")
+        direct = _direct_targets((gamma, beta), None)
+        adjacent = direct is not None and gamma.grad.data_ptr() + 4 * C == beta.grad.data_ptr()
+        red = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
+        dy = torch.empty_like(y)
+        L.check(L.lib().seld_bn_relu_pool_bwd(L.ptr(dpooled), L.ptr(pooled), L.ptr(idx), L.ptr(y), N, C, Hh, Ww, ph, pw,
+                                              L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(training),
+                                              L.ptr(red), L.ptr(dy), L.current_stream()), "seld_bn_relu_pool_bwd")
+        if adjacent:
+            # one add into the flat gradient slice [dgamma | dbeta] instead of two autograd accumulations
+            axpy_(gamma.grad, red, 2 * C)
+            return dy, None, None, None, None, None, None, None, None, None, None
+        return dy, red[:C], red[C:], None, None, None, None, None, None, None, None
+
+
+def axpy_(dst_first, src, n):
+    """dst[0:n] += src[0:n] where dst_first is the first of several tensors that are adjacent in one flat buffer."""
+    L.check(L.lib().seld_accumulate(L.ptr(dst_first), L.ptr(src), ctypes.c_int64(n), L.current_stream()), "seld_accumulate")
+
+
+def bn_relu_pool(y, bn, ph, pw, stats=None):
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BnReluPoolFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
+                              bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(ph), int(pw), stats)

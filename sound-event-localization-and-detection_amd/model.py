@@ -211,6 +211,29 @@ class TC_Block(nn.Module):
         return out
 
 
+class _CnnStage(nn.Sequential):
+    """[conv3x3, BatchNorm2d, ReLU, MaxPool2d, Dropout] with the reference's sub-module indices (model.py:269-283);
+    `forward` runs the fused path: conv (+ batch statistics in its epilogue) -> BN+ReLU+MaxPool in one pass -> dropout."""
+
+    def forward(self, x):
+        mods = list(self)
+        conv = mods[0]
+        if isinstance(mods[1], hnn.BatchNorm2d):
+            bn, pool = mods[1], mods[3]
+            s, p, d = _geom(conv)
+            ph, pw = hnn._window(pool.kernel_size, 2)
+            if bn.training:
+                y, stats = H.hyper_conv_stats(x, _components(conv), conv.bias, s, p, d)
+            else:
+                y, stats = H.hyper_conv(x, _components(conv), conv.bias, s, p, d), None
+            x = H.bn_relu_pool(y, bn, ph, pw, stats)
+            return mods[4](x)
+        x = conv(x)
+        for m in mods[1:]:
+            x = m(x)
+        return x
+
+
 class ConvTC_Block(nn.Module):
     """3 x [conv3x3 -> BN -> ReLU -> MaxPool(f, 1) -> Dropout] then the TCN (model.py:234-322)."""
 
@@ -237,7 +260,7 @@ class ConvTC_Block(nn.Module):
             if batch_norm in _CNN_BN:
                 layers.append(hnn.BatchNorm2d(c))
             layers += [hnn.ReLU(), hnn.MaxPool2d(pool), hnn.Dropout(dropout_perc)]
-            stages.append(nn.Sequential(*layers))
+            stages.append(_CnnStage(*layers))
             in_chans = c
         self.cnn = nn.Sequential(*stages)
         Lc = int(freq_dim / np.prod(np.array(pool_size), axis=0)[0] * cnn_filters[-1])
@@ -247,21 +270,8 @@ class ConvTC_Block(nn.Module):
                             batch_norm=batch_norm, kernel_size_dilated_conv=kernel_size_dilated_conv, verbose=verbose,
                             attention_type=attention_type, key_size=key_size, value_size=value_size)
 
-    def _stage(self, stage, x):
-        mods = list(stage)
-        conv = mods[0]
-        x = conv(x)
-        i = 1
-        if isinstance(mods[i], hnn.BatchNorm2d):
-            x = H.bn_act(x, mods[i], L.SELD_ACT_RELU)       # BN + ReLU in one pass
-            i += 2
-        for m in mods[i:]:
-            x = m(x)
-        return x
-
     def forward(self, x):
-        for stage in self.cnn:
-            x = self._stage(stage, x)
+        x = self.cnn(x)
         # (B, C, F', T) -> (B, C*F', T): the permute/reshape/permute of model.py:302-310 is a pure
         # relabelling of a contiguous NCHW tensor (channel index c*F' + f)
         B, C, Fp, T = x.shape

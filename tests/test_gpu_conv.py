@@ -94,9 +94,10 @@ def test_conv_epilogues():
     desc = H.make_conv_desc(tuple(x.shape), 64, 8, (1,), 1, 0, 1)
     base = H.conv_fwd(desc, x, ws)
     addend = torch.randn(2, 64, 64, generator=gen).to(dev)
-    stats = torch.zeros(128, device=dev)
-    y = H.conv_fwd(desc, x, ws, epilogue=L.SELD_EPI_ADD | L.SELD_EPI_STATS, addend=addend, stats=stats)
+    stats_rep = H.new_stats(64, dev)
+    y = H.conv_fwd(desc, x, ws, epilogue=L.SELD_EPI_ADD | L.SELD_EPI_STATS, addend=addend, stats=stats_rep)
     torch.cuda.synchronize()
+    stats = stats_rep.view(H.STATS_REPLICAS, 128).sum(0)
     assert torch.allclose(y, base + addend, atol=1e-5)
     ref = (base + addend).double()
     assert torch.allclose(stats[:64].double().cpu(), ref.sum(dim=(0, 2)).cpu(), rtol=1e-4, atol=1e-3)
