@@ -20,6 +20,7 @@ struct ConvP {
     int srcS, dstS;
     long long Ptot;            // N * dstS
     long long src_elems;       // N * Csrc * srcS
+    int pairing;               // allow primal/dual paired channel tiles (work balance)
     int wt;                    // dgrad: component tensors are transposed to [c][o][k]
     int skip_mode;             // 0 none, 1 (fwd DQ): low-half channels x high-half K is zero, 2 (dgrad DQ): high x low
     int epilogue;

@@ -108,13 +108,28 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
     const bool hok0 = pvalid && ((unsigned)base_h < (unsigned)p.srcH);
     const int rowb0 = img_b + base_h * srcWb;
 
+    // ---- channel tile of this workgroup -----------------------------------------------------------
+    // Dual quaternion: the first half of the channels (primal part) sees a structurally-zero K half.  So
+    // that every workgroup carries the same work, a workgroup MAY take BC/2 primal channels and the BC/2 dual
+    // channels at the same offset in the upper half (local tile j < CT/2 primal, j >= CT/2 dual) whenever
+    // the shape allows; otherwise tiles are contiguous.
+    const int half_c = p.Cdst >> 1;
+    const int half_k = p.Ktot >> 1;
+    const bool halves_aligned = (p.skip_mode != 0) && (half_k % 16 == 0) && (half_c % 16 == 0);
+    const bool paired = p.pairing && halves_aligned && (CT % 2 == 0) && (half_c % (BC / 2) == 0);
+    auto chan_of = [&](int t) __attribute__((always_inline)) {
+        if (!paired) return c0 + t;
+        const int base = blockIdx.y * (BC / 2);
+        return t < BC / 2 ? base + t : half_c + base + (t - BC / 2);
+    };
+
     // ---- per-lane decode of the weight rows this lane stages ---------------------------------------
     int w_a[WR], w_off[WR];        // fwd: a = output component p, off = o*CK ; dgrad: a = input component q, off = c*KK
     bool w_ok[WR];
 #pragma unroll
     for (int j = 0; j < WR; ++j) {
         const int ch = lane + 64 * j;
-        const int chg = c0 + ch;
+        const int chg = chan_of(ch);
         w_ok[j] = (ch < BC) && (chg < p.Cdst);
         const int cc = w_ok[j] ? chg : 0;
         if (MODE == MODE_FWD) {
@@ -127,18 +142,15 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
     }
 
     // ---- K range of this workgroup (dual-quaternion zero quadrant) ----------------------------------
-    const int half_c = p.Cdst >> 1;
-    const int half_k = p.Ktot >> 1;
-    const bool halves_aligned = (p.skip_mode != 0) && (half_k % 16 == 0) && (half_c % 16 == 0);
     int kbeg = 0, kend = p.Ktot;
-    if (halves_aligned) {
+    if (halves_aligned && !paired) {
         if (p.skip_mode == 1 && c0 + BC <= half_c) kend = half_k;      // all channels primal
         if (p.skip_mode == 2 && c0 >= half_c) kbeg = half_k;           // all channels dual
     }
     const int nchunks = (kend - kbeg + 15) >> 4;
-    // workgroup whose tiles straddle the primal/dual boundary exactly in the middle: half of its tiles skip
-    // the zero quadrant's chunks (other straddles just multiply by the staged zeros)
-    const bool mixed_wg = halves_aligned && (CT % 2 == 0) && (c0 + BC / 2 == half_c);
+    // workgroup whose lower tiles are primal and upper tiles dual: half of its tiles skip the zero quadrant's
+    // chunks (any other straddle just multiplies by the staged zeros)
+    const bool mixed_wg = paired || (halves_aligned && (CT % 2 == 0) && (c0 + BC / 2 == half_c));
 
     // ---- scalar trackers of this wave's weight k-group start kw = kbeg + 16*chunk + 4*wave ----------
     // fwd  : kw = kq*CK + kl           (input component, local index)
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
     }
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
-        const int ch = c0 + j * 16 + fr;
+        const int ch = chan_of(j * 16 + fr);
         const bool chok = ch < p.Cdst;
         const float bvv = (chok && p.bias) ? p.bias[ch] : 0.0f;
         float s1 = 0.f, s2 = 0.f;
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
         const float* redbuf = &Xs[0][0][0][0];
         float* rep = p.stats + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
         for (int t = tid; t < BC; t += 256) {
-            const int ch = c0 + t;
+            const int ch = chan_of(t);
             if (ch < p.Cdst) {
                 float a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -502,6 +514,7 @@ static int run_conv(ConvP& p, hipStream_t st) {
 
 static void fill_common(ConvP& p, const seld_conv_desc* d, const float* const w[8]) {
     p.algebra = d->algebra;
+    p.pairing = getenv("SELD_CONV_PAIR") ? 1 : 0;   // measured 5-14 % slower on the TCN layers: off by default
     p.KH = d->k[0]; p.KW = d->k[1];
     p.OA = d->Cout / d->algebra; p.IA = d->Cin / d->algebra;
     for (int i = 0; i < 8; ++i) p.w.p[i] = (i < d->algebra) ? w[i] : nullptr;

@@ -239,7 +239,9 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, long 
     long long Ktot = (long long)d->Cin * d->k[0] * d->k[1];
     long long tiles = ((d->Cout + bm - 1) / bm) * ((Ktot + bn - 1) / bn);
     if (d->algebra == 8) tiles = tiles * 3 / 4 > 0 ? tiles * 3 / 4 : 1;   // zero-quadrant tiles exit at once
-    long long want = (768 + tiles - 1) / tiles;           // ~3 workgroups per CU
+    long long target = 768;                               // ~3 workgroups per CU
+    if (const char* e = getenv("SELD_WGRAD_WGS")) target = atoll(e) > 0 ? atoll(e) : target;
+    long long want = (target + tiles - 1) / tiles;
     long long maxs = (Ptot + 511) / 512;                  // at least 512 positions per split
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
