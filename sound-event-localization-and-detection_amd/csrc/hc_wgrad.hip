@@ -207,6 +207,192 @@ __global__ __launch_bounds__(256) void hc_wgrad_kernel(const WgradP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fast variant for stride-1-along-W convolutions whose output rows are a multiple of 4 wide (every shape
+// of the SELD models).  Same GEMM, but the K step is 32 positions and the staging is COALESCED: 8 lanes
+// cover the 128 contiguous bytes a row contributes to a step (the kernel above lets each lane walk its own
+// row, i.e. 64 different cache lines per load instruction).  Each lane tracks the (image, row, column) of
+// its own 4-position group incrementally.
+// ------------------------------------------------------------------------------------------
+template <int WRW, int RT, int CTL, int KH_T, int KW_T>
+__global__ __launch_bounds__(256) void hc_wgrad32_kernel(const WgradP p) {
+    constexpr int WCW = 4 / WRW;
+    constexpr int BM = WRW * RT * 16;
+    constexpr int BN = WCW * CTL * 16;
+    constexpr int AR = (BM + 31) / 32;       // rows staged per thread (32 rows per pass)
+    constexpr int BR = (BN + 31) / 32;
+    __shared__ __attribute__((aligned(16))) float As[2][8][BM][4];   // dy   [k-group][co][4 positions]
+    __shared__ __attribute__((aligned(16))) float Bs[2][8][BN][4];   // xcol [k-group][col][4 positions]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr_ = wave / WCW, wc_ = wave % WCW;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int split = blockIdx.z;
+    const int KH = KH_T ? KH_T : p.KH;
+    const int KW = KW_T ? KW_T : p.KW;
+    const int KK = KH * KW;
+    const int CK = p.IA * KK;
+
+    if (p.algebra == 8 && m0 + BM <= (p.Cout >> 1) && n0 >= (p.Ktot >> 1)) return;   // zero quadrant
+
+    const long long pbeg = (long long)split * p.split_len;
+    long long pend = pbeg + p.split_len;
+    if (pend > p.Ptot) pend = p.Ptot;
+    const int nchunks = pbeg < pend ? (int)((pend - pbeg + 31) >> 5) : 0;
+
+    const int g = tid & 7;                   // 4-position group inside the 32-position step
+    const int rsub = tid >> 3;               // 0..31
+
+    bool a_ok[AR];
+    int a_off[AR];                           // co * outS
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        const int r = rsub + 32 * j;
+        a_ok[j] = r < BM && (m0 + r) < p.Cout;
+        a_off[j] = a_ok[j] ? (m0 + r) * p.outS : 0;
+    }
+    bool b_ok[BR];
+    int b_coff[BR], b_dh[BR], b_dw[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int c = rsub + 32 * j;
+        const int kk = n0 + c;
+        b_ok[j] = c < BN && kk < p.Ktot;
+        const int kkc = b_ok[j] ? kk : 0;
+        const int ci = kkc / KK;
+        const int kidx = kkc - ci * KK;
+        const int kh = kidx / KW, kw = kidx - kh * KW;
+        b_coff[j] = ci * p.inS;
+        b_dh[j] = kh * p.dh - p.ph;
+        b_dw[j] = kw * p.dw - p.pw;
+    }
+
+    // per-lane tracker of this lane's group start: position pbeg + 32*chunk + 4*g = (img, oh, ow)
+    long long t_pos = pbeg + 4 * g;
+    int t_img, t_oh, t_ow;
+    {
+        const long long im = t_pos / p.outS;
+        const int rem = (int)(t_pos - im * p.outS);
+        t_img = (int)im;
+        t_oh = rem / p.outW;
+        t_ow = rem - t_oh * p.outW;
+    }
+    const size_t dy_img = (size_t)p.Cout * p.outS;
+    const size_t x_img = (size_t)p.Cin * p.inS;
+    const int img_first = (int)(pbeg / p.outS);                    // scalar: first image of this split
+    const long long x_remain = ((long long)p.N - img_first) * (long long)x_img * 4;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (size_t)img_first * x_img), 0, x_remain > 0xFFFFFFFFLL ? 0xFFFFFFFFu : (unsigned)x_remain, 0x00020000);
+
+    float ar[AR][4], br[BR][4];
+
+    auto load_chunk = [&](int) __attribute__((always_inline)) {
+        const bool pin = t_pos < pend;          // outW % 4 == 0: the group's 4 positions share row and validity
+        const float* dyb = p.dy + (size_t)t_img * dy_img + (size_t)t_oh * p.outW + t_ow;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pin && a_ok[j]) v = *reinterpret_cast<const float4*>(dyb + a_off[j]);
+            ar[j][0] = v.x; ar[j][1] = v.y; ar[j][2] = v.z; ar[j][3] = v.w;
+        }
+        // x gather through a buffer descriptor based at this split's first image: an invalid tap gets the
+        // offset 0xFFFFFFFF, which the hardware range check turns into 0.0 (no exec-mask juggling)
+        const int xoff = (t_img - img_first) * (int)x_img;
+        const int hh = t_oh * p.sh, ww = t_ow;          // sw == 1
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int ih = hh + b_dh[j], iw = ww + b_dw[j];
+            const bool rowok = pin && b_ok[j] && (unsigned)ih < (unsigned)p.inH;
+            const int base = (xoff + b_coff[j] + ih * p.inW + iw) * 4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned off = (rowok && (unsigned)(iw + s) < (unsigned)p.inW) ? (unsigned)(base + 4 * s) : 0xFFFFFFFFu;
+                br[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, 0, 0));
+            }
+        }
+        // advance by 32 positions
+        t_pos += 32;
+        t_ow += 32;
+        while (t_ow >= p.outW) {
+            t_ow -= p.outW;
+            if (++t_oh >= p.outH) { t_oh = 0; ++t_img; }
+        }
+    };
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            const int r = rsub + 32 * j;
+            if (r < BM) *reinterpret_cast<float4*>(&As[buf][g][r][0]) = make_float4(ar[j][0], ar[j][1], ar[j][2], ar[j][3]);
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int c = rsub + 32 * j;
+            if (c < BN) *reinterpret_cast<float4*>(&Bs[buf][g][c][0]) = make_float4(br[j][0], br[j][1], br[j][2], br[j][3]);
+        }
+    };
+
+    floatx4 acc[RT][CTL];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CTL; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fk = lane >> 4;
+    if (nchunks > 0) { load_chunk(0); store_chunk(0); }
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float av[RT][4], bv[CTL][4];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(&As[buf][half * 4 + fk][wr_ * (RT * 16) + i * 16 + fr][0]);
+                av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < CTL; ++j) {
+                const float4 t = *reinterpret_cast<const float4*>(&Bs[buf][half * 4 + fk][wc_ * (CTL * 16) + j * 16 + fr][0]);
+                bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CTL; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < CTL; ++j) {
+        const int kk = n0 + wc_ * (CTL * 16) + j * 16 + fr;
+        if (kk >= p.Ktot) continue;
+        const int qq = kk / CK;
+        const int ckl = kk - qq * CK;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m0 + wr_ * (RT * 16) + i * 16 + fk * 4 + r;
+                if (co >= p.Cout) continue;
+                const int pp = co / p.OA;
+                const int o = co - pp * p.OA;
+                bool zero, neg;
+                const int comp = hc_comp(p.algebra, pp, qq, &zero, &neg);
+                if (zero) continue;
+                const float v = acc[i][j][r];
+                atomicAdd(p.gw.p[comp] + (size_t)o * CK + ckl, neg ? -v : v);
+            }
+        }
+    }
+}
+
 // per-channel sum over (N, S): dbias  (accumulates)
 __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, int S, float* __restrict__ out) {
     const int c = blockIdx.x;
@@ -247,7 +433,7 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, long 
     if (want < 1) want = 1;
     if (want > 1024) want = 1024;
     long long len = (Ptot + want - 1) / want;
-    len = (len + 15) / 16 * 16;
+    len = (len + 31) / 32 * 32;
     int ns = (int)((Ptot + len - 1) / len);
     *split_len = len;
     return ns < 1 ? 1 : ns;
@@ -256,19 +442,42 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, long 
 // tile configuration: 0 = 128 x 128 (waves 2 x 2), 1 = 192 x 80 for short K (first layer), 2 = 64 x 64 (small layers)
 static int wgrad_cfg(const seld_conv_desc* d) {
     const int Ktot = d->Cin * d->k[0] * d->k[1];
+    if (const char* e = getenv("SELD_WGRAD_CFG")) return atoi(e);     // tuning aid
     if (Ktot <= 80 && d->Cout > 64) return 1;
     if (d->Cout <= 64 || Ktot <= 64) return 2;
+    // few 128 x 128 tiles and a short reduction (positions / 512 splits at most): take 64 x 64 tiles so that
+    // the launch still has >= 2 workgroups per CU
+    int o[2];
+    hc_out_shape(d, o);
+    const long long P = (long long)d->N * o[0] * o[1];
+    const long long tiles128 = (long long)((d->Cout + 127) / 128) * ((Ktot + 127) / 128);
+    const long long splits = (P + 511) / 512;
+    if (tiles128 * (splits < 48 ? splits : 48) < 512) return 2;
+    // dual quaternion: 96-row tiles end exactly on the primal/dual boundary when Cout/2 is a multiple of 96,
+    // so the whole zero quadrant is skipped (128-row tiles straddle it)
+    if (d->algebra == 8 && (d->Cout / 2) % 96 == 0) return 3;
     return 0;
+}
+
+static bool wgrad_fast_ok(const WgradP& p) {
+    return (p.outW % 4 == 0) && p.sw == 1 && !getenv("SELD_WGRAD_SLOW");
 }
 
 template <int WRW, int RT, int CTL>
 static void launch_wgrad(const WgradP& p, hipStream_t st) {
     constexpr int BM = WRW * RT * 16, BN = (4 / WRW) * CTL * 16;
     dim3 grid((p.Ktot + BN - 1) / BN, (p.Cout + BM - 1) / BM, p.nsplit);
-    if (p.KH == 1 && p.KW == 1) hipLaunchKernelGGL((hc_wgrad_kernel<WRW, RT, CTL, 1, 1>), grid, dim3(256), 0, st, p);
-    else if (p.KH == 1 && p.KW == 3) hipLaunchKernelGGL((hc_wgrad_kernel<WRW, RT, CTL, 1, 3>), grid, dim3(256), 0, st, p);
-    else if (p.KH == 3 && p.KW == 3) hipLaunchKernelGGL((hc_wgrad_kernel<WRW, RT, CTL, 3, 3>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((hc_wgrad_kernel<WRW, RT, CTL, 0, 0>), grid, dim3(256), 0, st, p);
+    const bool fast = wgrad_fast_ok(p);
+#define SELD_WG(KH_, KW_)                                                                                         \
+    do {                                                                                                          \
+        if (fast) hipLaunchKernelGGL((hc_wgrad32_kernel<WRW, RT, CTL, KH_, KW_>), grid, dim3(256), 0, st, p);      \
+        else hipLaunchKernelGGL((hc_wgrad_kernel<WRW, RT, CTL, KH_, KW_>), grid, dim3(256), 0, st, p);            \
+    } while (0)
+    if (p.KH == 1 && p.KW == 1) SELD_WG(1, 1);
+    else if (p.KH == 1 && p.KW == 3) SELD_WG(1, 3);
+    else if (p.KH == 3 && p.KW == 3) SELD_WG(3, 3);
+    else SELD_WG(0, 0);
+#undef SELD_WG
 }
 
 static int wgrad_run(const seld_conv_desc* d, const float* x, const float* dy, float* const dw[8], float* dbias,
@@ -303,6 +512,7 @@ static int wgrad_run(const seld_conv_desc* d, const float* x, const float* dy, f
     const int cfg = wgrad_cfg(d);
     if (cfg == 0) { p.nsplit = wgrad_splits(d, o, 128, 128, &p.split_len); launch_wgrad<2, 4, 4>(p, st); }
     else if (cfg == 1) { p.nsplit = wgrad_splits(d, o, 192, 80, &p.split_len); launch_wgrad<4, 3, 5>(p, st); }
+    else if (cfg == 3) { p.nsplit = wgrad_splits(d, o, 96, 128, &p.split_len); launch_wgrad<2, 3, 4>(p, st); }
     else { p.nsplit = wgrad_splits(d, o, 64, 64, &p.split_len); launch_wgrad<2, 2, 2>(p, st); }
     rc = check_launch();
     if (rc) return rc;
@@ -317,8 +527,11 @@ int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
     int kh = d->k[0], kw = d->k[1];
     if (!((kh == 1 && kw == 1) || (kh == 1 && kw == 3) || (kh == 3 && kw == 3))) kh = kw = 0;
     const int cfg = wgrad_cfg(d);
-    const char* t = cfg == 0 ? "2, 4, 4" : (cfg == 1 ? "4, 3, 5" : "2, 2, 2");
-    snprintf(buf, buflen, "hc_wgrad_kernel<%s, %d, %d>", t, kh, kw);
+    const char* t = cfg == 0 ? "2, 4, 4" : (cfg == 1 ? "4, 3, 5" : (cfg == 3 ? "2, 3, 4" : "2, 2, 2"));
+    int o[2];
+    hc_out_shape(d, o);
+    const bool fast = (o[1] % 4 == 0) && d->stride[1] == 1 && !getenv("SELD_WGRAD_SLOW");
+    snprintf(buf, buflen, "%s<%s, %d, %d>", fast ? "hc_wgrad32_kernel" : "hc_wgrad_kernel", t, kh, kw);
     return SELD_OK;
 }
 
