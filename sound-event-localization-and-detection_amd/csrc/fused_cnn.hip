@@ -24,13 +24,14 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
                                                                float* __restrict__ pooled, uint8_t* __restrict__ idx) {
-    const long long total = g.NC * g.OH * g.OW;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int ow = (int)(i % g.OW);
-        const long long t = i / g.OW;
-        const int oh = (int)(t % g.OH);
-        const long long nc = t / g.OH;
+    // grid: (ceil(OW / 256), OH, N*C): no index division on the hot path, channel constants are wave-uniform
+    {
+        const int ow = blockIdx.x * blockDim.x + threadIdx.x;
+        if (ow >= g.OW) return;
+        const int oh = blockIdx.y;
+        const long long nc = blockIdx.z;
         const int c = (int)(nc % g.C);
+        const long long i = (nc * g.OH + oh) * g.OW + ow;
         const float a = gamma[c] * invstd[c];
         const float b = beta[c] - mean[c] * a;
         const float* base = y + ((size_t)nc * g.H + (size_t)oh * g.ph) * g.W + (size_t)ow * g.pw;
@@ -107,12 +108,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_kernel(const float
                                                                      int train, float* __restrict__ dy) {
     // one thread per (nc, oh', ow') where oh' also covers the rows that floor-mode pooling drops
     const int OHx = (g.H + g.ph - 1) / g.ph, OWx = (g.W + g.pw - 1) / g.pw;
-    const long long total = g.NC * OHx * OWx;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int ow = (int)(i % OWx);
-        const long long t = i / OWx;
-        const int oh = (int)(t % OHx);
-        const long long nc = t / OHx;
+    {
+        const int ow = blockIdx.x * blockDim.x + threadIdx.x;
+        if (ow >= OWx) return;
+        const int oh = blockIdx.y;
+        const long long nc = blockIdx.z;
         const int c = (int)(nc % g.C);
         const float mu = mean[c], is = invstd[c];
         const float a = gamma[c] * is;
@@ -151,6 +151,7 @@ using namespace seld;
 
 static int mk_geom(PoolGeom& g, int N, int C, int H, int W, int ph, int pw) {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || ph * pw > 255 || H < ph || W < pw) return SELD_EINVAL;
+    if ((long long)N * C > 65535 || (H + ph - 1) / ph > 65535) return SELD_EUNSUPPORTED;   // grid.z / grid.y limits
     g.NC = (long long)N * C; g.C = C; g.H = H; g.W = W; g.ph = ph; g.pw = pw; g.OH = H / ph; g.OW = W / pw;
     return SELD_OK;
 }
@@ -162,7 +163,7 @@ extern "C" int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32
     int rc = mk_geom(g, N, C, H, W, ph, pw);
     if (rc) return rc;
     if (!y || !mean || !invstd || !gamma || !beta || !pooled || !idx) return SELD_EINVAL;
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(grid_cap(g.NC * g.OH * g.OW)), dim3(256), 0, (hipStream_t)stream, y, g,
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((g.OW + 255) / 256, g.OH, (unsigned)g.NC), dim3(256), 0, (hipStream_t)stream, y, g,
                        mean, invstd, gamma, beta, pooled, idx);
     return check_launch();
 }
@@ -183,7 +184,7 @@ extern "C" int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, 
     rc = check_launch();
     if (rc) return rc;
     const int OHx = (H + ph - 1) / ph, OWx = (W + pw - 1) / pw;
-    hipLaunchKernelGGL(bn_relu_pool_bwd_apply_kernel, dim3(grid_cap(g.NC * OHx * OWx)), dim3(256), 0, st, dpooled, pooled, idx, y,
+    hipLaunchKernelGGL(bn_relu_pool_bwd_apply_kernel, dim3((OWx + 255) / 256, OHx, (unsigned)g.NC), dim3(256), 0, st, dpooled, pooled, idx, y,
                        g, mean, invstd, gamma, red, 1.0f / (float)((long long)N * H * W), train, dy);
     return check_launch();
 }

@@ -512,6 +512,8 @@ static int run_conv(ConvP& p, hipStream_t st) {
     return check_launch();
 }
 
+int hc_conv_smallk_try(const ConvP& p, hipStream_t st, int* rc, int dry_run);
+
 static void fill_common(ConvP& p, const seld_conv_desc* d, const float* const w[8]) {
     p.algebra = d->algebra;
     p.pairing = getenv("SELD_CONV_PAIR") ? 1 : 0;   // measured 5-14 % slower on the TCN layers: off by default
@@ -555,6 +557,9 @@ extern "C" int seld_hc_conv_fwd_ex(const seld_conv_desc* d, const float* x, cons
     p.skip_mode = (d->algebra == 8) ? 1 : 0;
     p.epilogue = epilogue;
     p.src = x; p.bias = bias; p.dst = y; p.addend = addend; p.stats = stats;
+    int rc2 = SELD_OK;
+    if (const char* e = getenv("SELD_SMALLK_DBG")) p.wt = atoi(e);
+    if (hc_conv_smallk_try(p, (hipStream_t)stream, &rc2, 0)) return rc2;       // short reductions: persistent kernel
     return run_conv<MODE_FWD>(p, (hipStream_t)stream);
 }
 
@@ -626,6 +631,20 @@ extern "C" int seld_hc_conv_kernel_label(const seld_conv_desc* d, int32_t which,
     int o[2];
     hc_out_shape(d, o);
     const long long P = which == 0 ? (long long)d->N * o[0] * o[1] : (long long)d->N * d->in[0] * d->in[1];
+    if (which == 0 && d->stride[0] == 1 && d->stride[1] == 1) {
+        ConvP p{};
+        p.mode = MODE_FWD; p.algebra = d->algebra; p.SDh = p.SDw = p.SMh = p.SMw = 1;
+        p.Ktot = d->Cin * d->k[0] * d->k[1]; p.Cdst = d->Cout; p.dstS = o[0] * o[1]; p.Ptot = P;
+        p.src_elems = (long long)d->N * d->Cin * d->in[0] * d->in[1];
+        p.epilogue = 0;
+        int dummy;
+        const int ct = hc_conv_smallk_try(p, nullptr, &dummy, 1);
+        if (ct) {
+            const bool t33 = d->k[0] == 3 && d->k[1] == 3, t13 = d->k[0] == 1 && d->k[1] == 3;
+            snprintf(buf, buflen, "hc_conv_smallk_kernel<%d, %d, %d>", ct, t33 ? 3 : (t13 ? 1 : 0), (t33 || t13) ? 3 : 0);
+            return SELD_OK;
+        }
+    }
     const TileCfg c = pick_cfg(which == 0 ? d->Cout : d->Cin, P);
     snprintf(buf, buflen, "hc_conv_kernel<%d, %d, %d, %d, %d>", c.ct, c.pt, kh, kw, which);
     return SELD_OK;

@@ -1,0 +1,260 @@
+// Hypercomplex convolution forward for SHORT reductions (Cin * kh * kw <= 160), gfx950: the first CNN layer.
+//
+// For `cnn.0` (8 -> 192 channels, 3x3, 52 MB and 1.36 GFLOP per sample, model.py:273-274) the reduction is
+// only 72 deep, so the general kernel's K loop is all prologue: it ran latency-bound at ~1.1 TB/s while the
+// layer's roof is the 1.6 GB output write.  This variant is persistent and weight-stationary:
+//   * one 8-wave workgroup per CU keeps the WHOLE expanded, signed weight tile [K/4][Cout][4] in LDS (55 KB)
+//     for its lifetime -- the Hamilton assembly happens once per workgroup, not once per tile;
+//   * it walks 128-position tiles; the im2col image of tile t+1 (18 KB) is gathered with buffer loads
+//     (hardware zero-fill for the halo) into registers while tile t is multiplied, then dropped into the
+//     other half of a double-buffered LDS image: one barrier per tile;
+//   * MFMA granularity is one k-group (4 taps) per v_mfma_f32_16x16x4_f32 with ds_read_b32 operands, so the
+//     72-deep reduction costs exactly 18 MFMAs and the primal output channels stop after the 9 groups that
+//     are not structurally zero (162 instead of 240 MFMAs per 16 x 192 output tile);
+//   * each lane stores 4 consecutive positions of a channel (16-byte stores); BatchNorm statistics are kept in
+//     registers across tiles and leave the workgroup as ONE set of atomics.
+#include "hc_common.h"
+
+namespace seld {
+
+// Waves per workgroup.  4-wave workgroups, two per CU (each with its own copy of the weights in LDS), run out of
+// phase with each other, so one workgroup's stores / gathers hide under the other's MFMAs; an 8-wave workgroup
+// per CU keeps its two waves per SIMD in lock-step.  SELD_SMALLK_NW=8 selects the latter (tuning aid).
+template <int NW> struct SkGeom { static constexpr int TP = NW * 16, NT = NW * 64; };
+
+template <int CT, int KH_T, int KW_T, int SK_NW>
+__global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP p, int NG, int NGP, long long ntiles) {
+    constexpr int BC = CT * 16;
+    constexpr int SK_TP = SkGeom<SK_NW>::TP, SK_NT = SkGeom<SK_NW>::NT;
+    constexpr bool DB = (SK_NW == 8);                    // double-buffered X image (4-wave variant: single buffer, two barriers)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;                                    // [NG][BC][4]
+    float* Xs = smem + (size_t)NG * BC * 4;              // [2][NG][SK_TP][4]
+    __shared__ const float* wptr_s[8];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int KH = KH_T ? KH_T : p.KH;
+    const int KW = KW_T ? KW_T : p.KW;
+    const int KK = KH * KW;
+    const int A = p.algebra;
+    const int CK = p.IA * KK;
+
+    if (tid < 8) wptr_s[tid] = p.w.p[tid];
+    __syncthreads();
+
+    // ---- weights: expanded + signed, once per workgroup ------------------------------------------------
+    for (int idx = tid; idx < NG * BC; idx += SK_NT) {
+        const int g = idx / BC, ch = idx - g * BC;
+        const int pp = ch / p.OA, o = ch - pp * p.OA;
+        float v[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kk = g * 4 + s;
+            float x = 0.f;
+            if (kk < p.Ktot) {
+                const int qq = kk / CK, l = kk - qq * CK;
+                bool zero, neg;
+                const int comp = hc_comp(A, pp, qq, &zero, &neg);
+                if (!zero) {
+                    x = wptr_s[comp][o * CK + l];
+                    if (neg) x = -x;
+                }
+            }
+            v[s] = x;
+        }
+        *reinterpret_cast<float4*>(&Ws[(size_t)idx * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.src, 0, (unsigned)(p.src_elems * 4 > 0xFFFFFFFFLL ? 0xFFFFFFFFu : p.src_elems * 4), 0x00020000);
+
+    // im2col items of one tile: (g, pos), pos = tid & 127 for every item of this thread, g = (tid >> 7) + 4*i
+    const int xpos = tid & (SK_TP - 1);
+    const int xg0 = __builtin_amdgcn_readfirstlane(tid / SK_TP);
+    constexpr int XI_MAX = 10;                           // NG <= 40
+    const int xi_n = (NG - xg0 + 3) / 4;                 // items of this thread
+    float xr[XI_MAX][4];
+
+    auto gather = [&](long long tile) __attribute__((always_inline)) {
+        const unsigned pos = (unsigned)(tile * SK_TP) + xpos;
+        const bool pvalid = pos < (unsigned)p.Ptot;
+        const unsigned img = pos / (unsigned)p.dstS;
+        const unsigned rem = pos - img * (unsigned)p.dstS;
+        const int oh = rem / (unsigned)p.dstW;
+        const int ow = rem - oh * p.dstW;
+        const int base_h = oh + p.OFFh, base_w = ow + p.OFFw;      // stride 1
+        const unsigned img_b = img * (unsigned)(p.Csrc * p.srcS) * 4u;
+#pragma unroll
+        for (int i = 0; i < XI_MAX; ++i) {
+            if (i < xi_n) {
+                const int g = xg0 + 4 * i;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int kk = g * 4 + s;
+                    const int kkc = kk < p.Ktot ? kk : 0;
+                    const int chan = kkc / KK;
+                    const int kidx = kkc - chan * KK;
+                    const int kh = kidx / KW, kw = kidx - kh * KW;
+                    const int ih = base_h + kh * p.KDh, iw = base_w + kw * p.KDw;
+                    const bool ok = pvalid && kk < p.Ktot && (unsigned)ih < (unsigned)p.srcH && (unsigned)iw < (unsigned)p.srcW;
+                    const unsigned off = ok ? img_b + (unsigned)((chan * p.srcS + ih * p.srcW + iw) * 4) : 0xFFFFFFFFu;
+                    xr[i][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+                }
+            }
+        }
+    };
+    auto scatter = [&](int buf) __attribute__((always_inline)) {
+        float* dst = Xs + (size_t)buf * NG * SK_TP * 4;
+#pragma unroll
+        for (int i = 0; i < XI_MAX; ++i)
+            if (i < xi_n)
+                *reinterpret_cast<float4*>(&dst[((size_t)(xg0 + 4 * i) * SK_TP + xpos) * 4]) =
+                    make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
+    };
+
+    float s1[CT], s2[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+    const int dbg = p.wt;      // experiment switches (wt is unused by the forward): 1 = no stores, 2 = no gathers
+    long long tile = blockIdx.x;
+    if (tile < ntiles) { gather(tile); scatter(0); }
+    __syncthreads();
+
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long long next = tile + gridDim.x;
+        if (next < ntiles && !(dbg & 2)) gather(next);
+
+        floatx4 acc[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        const float* xb = Xs + (size_t)buf * NG * SK_TP * 4 + (size_t)(wave * 16 + fr) * 4 + fk;
+        const float* wb = Ws + (size_t)fr * 4 + fk;
+        // groups every channel tile needs (unrolled x3 so that the next groups' LDS reads issue under the MFMAs)
+#pragma unroll 3
+        for (int g = 0; g < NGP; ++g) {
+            const float a = xb[(size_t)g * SK_TP * 4];
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[((size_t)g * BC + j * 16) * 4], acc[j], 0, 0, 0);
+        }
+        // groups in the structurally-zero K half of the primal channels: upper half of the tiles only
+#pragma unroll 3
+        for (int g = NGP; g < NG; ++g) {
+            const float a = xb[(size_t)g * SK_TP * 4];
+#pragma unroll
+            for (int j = CT / 2; j < CT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[((size_t)g * BC + j * 16) * 4], acc[j], 0, 0, 0);
+        }
+
+        // store: lane owns channel j*16+fr, positions tile*128 + wave*16 + fk*4 .. +3
+        const unsigned pos = (unsigned)(tile * SK_TP) + wave * 16 + fk * 4;
+        if (pos < (unsigned)p.Ptot) {
+            const unsigned img = pos / (unsigned)p.dstS;
+            const unsigned rem = pos - img * (unsigned)p.dstS;
+            float* drow = p.dst + (size_t)img * p.Cdst * p.dstS + rem;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int ch = j * 16 + fr;
+                const float bvv = p.bias ? p.bias[ch] : 0.f;
+                const float4 o = make_float4(acc[j][0] + bvv, acc[j][1] + bvv, acc[j][2] + bvv, acc[j][3] + bvv);
+                if (!(dbg & 1)) *reinterpret_cast<float4*>(drow + (size_t)ch * p.dstS) = o;
+                s1[j] += (o.x + o.y) + (o.z + o.w);
+                s2[j] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+            }
+        }
+        if (DB) {
+            if (next < ntiles) scatter(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        } else {
+            __syncthreads();                               // everyone is done reading the image
+            if (next < ntiles) scatter(0);
+            __syncthreads();
+        }
+    }
+
+    if (p.epilogue & SELD_EPI_STATS) {
+        // lanes fr, fr+16, fr+32, fr+48 hold the same channel; 8 waves hold different positions
+        float* red = Xs;                                   // free now: [SK_NW][BC][2]
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            float a = s1[j], b = s2[j];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (fk == 0) {
+                red[(wave * BC + j * 16 + fr) * 2 + 0] = a;
+                red[(wave * BC + j * 16 + fr) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        float* rep = p.stats + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
+        for (int t = tid; t < BC; t += SK_NT) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < SK_NW; ++wv) { a += red[(wv * BC + t) * 2]; b += red[(wv * BC + t) * 2 + 1]; }
+            atomicAdd(rep + t, a);
+            atomicAdd(rep + p.Cdst + t, b);
+        }
+    }
+}
+
+template <int CT, int NW>
+static int launch_smallk(const ConvP& p, int NG, int NGP, hipStream_t st) {
+    constexpr int TP = SkGeom<NW>::TP, NT = SkGeom<NW>::NT;
+    const long long ntiles = (p.Ptot + TP - 1) / TP;
+    const size_t smem = ((size_t)NG * CT * 16 * 4 + (size_t)(NW == 8 ? 2 : 1) * NG * TP * 4) * sizeof(float);
+    const long long want = 256 * (8 / NW);                 // one 8-wave or two 4-wave workgroups per CU
+    const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
+#define SELD_SK(KH_, KW_)                                                                                          \
+    do {                                                                                                           \
+        auto kern = hc_conv_smallk_kernel<CT, KH_, KW_, NW>;                                                       \
+        if (smem > 64 * 1024 &&                                                                                    \
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
+            return SELD_ELAUNCH;                                                                                   \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p, NG, NGP, ntiles);                              \
+    } while (0)
+    if (p.KH == 1 && p.KW == 3) SELD_SK(1, 3);
+    else if (p.KH == 3 && p.KW == 3) SELD_SK(3, 3);
+    else SELD_SK(0, 0);
+#undef SELD_SK
+    return check_launch();
+}
+
+// Returns the channel-tile count if the call is (dry_run: would be) handled here (rc in *rc), 0 if the general
+// kernel must be used.
+int hc_conv_smallk_try(const ConvP& p, hipStream_t st, int* rc, int dry_run) {
+    if (getenv("SELD_CONV_NO_SMALLK")) return 0;
+    if (p.mode != MODE_FWD || p.SDh != 1 || p.SDw != 1 || p.SMh != 1 || p.SMw != 1) return 0;
+    if (p.Ktot > 160 || (p.epilogue & ~SELD_EPI_STATS)) return 0;
+    if (p.dstS % 4 || p.Ptot >= (1LL << 31) || p.src_elems * 4 >= (1LL << 32)) return 0;
+    if (p.Ptot < 256 * 128) return 0;                         // not worth a persistent launch
+    const int NG = (p.Ktot + 3) / 4;
+    int NGP = NG;                                             // groups needed by every tile
+    if (p.algebra == 8 && (p.Ktot / 2) % 4 == 0 && (p.Cdst / 2) % 16 == 0) NGP = p.Ktot / 8;
+    int ct = 0;
+    if (p.Cdst == 192) ct = 12;
+    else if (p.Cdst == 128) ct = 8;
+    else if (p.Cdst == 64) ct = 4;
+    else return 0;
+    const int nw = (getenv("SELD_SMALLK_NW") && atoi(getenv("SELD_SMALLK_NW")) == 8) ? 8 : 4;
+    const size_t smem = ((size_t)NG * ct * 16 * 4 + (size_t)(nw == 8 ? 2 : 1) * NG * nw * 16 * 4) * sizeof(float);
+    if (smem * (8 / nw) > 156 * 1024) return 0;
+    if (dry_run) return ct;
+    if (nw == 8) {
+        if (ct == 12) *rc = launch_smallk<12, 8>(p, NG, NGP, st);
+        else if (ct == 8) *rc = launch_smallk<8, 8>(p, NG, NGP, st);
+        else *rc = launch_smallk<4, 8>(p, NG, NGP, st);
+    } else {
+        if (ct == 12) *rc = launch_smallk<12, 4>(p, NG, NGP, st);
+        else if (ct == 8) *rc = launch_smallk<8, 4>(p, NG, NGP, st);
+        else *rc = launch_smallk<4, 4>(p, NG, NGP, st);
+    }
+    return ct;
+}
+
+}  // namespace seld

@@ -53,6 +53,9 @@ def test_conv_matches_fixture_and_oracle(case, golden):
     (4, (2, 64, 77), 128, 3, 2, 2),         # odd length -> scalar epilogue path
     (1, (2, 24, 50), 40, 3, 1, 1),          # real-valued model
     (1, (2, 8, 9, 33), 16, (3, 3), 1, 1),
+    (8, (4, 8, 32, 512), 192, (3, 3), 1, 1),    # persistent short-reduction kernel (first CNN layer), 12 channel tiles
+    (4, (2, 8, 64, 512), 64, (3, 3), 1, 1),     # same kernel, quaternion model, 4 channel tiles
+    (8, (1, 16, 40, 1024), 128, (1, 3), (0, 2), (1, 2)),   # 1x3 dilated, 16-channel input, 8 channel tiles
 ])
 def test_conv_random_vs_oracle(algebra, shape, cout, k, pad, dil):
     import seld_amd
