@@ -30,7 +30,11 @@
 
 namespace seld {
 
-template <int CT, int PT, int KH_T, int KW_T, int MODE>
+// FAST = 1 fixes at compile time what the launcher has checked: weight rows contiguous along K (forward, or data
+// gradient with transposed weights), component extent CK a multiple of 4 and >= 16, no strided data gradient.
+// The staging code then has NO control flow (hipcc's waitcnt insertion is conservative at branch merges: with
+// the run-time branches it waited for the im2col loads before issuing the weight loads).
+template <int CT, int PT, int KH_T, int KW_T, int MODE, int FAST>
 __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
     constexpr int BC = CT * 16;
     constexpr int BP = PT * 64;
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
     const int A = p.algebra;
     // `lin`: the weight rows are contiguous along the K axis inside one component block (forward always; data
     // gradient when the caller supplied transposed component tensors Wt[c][o][k], p.wt)
-    const bool lin = (MODE == MODE_FWD) || (p.wt != 0);
+    const bool lin = FAST ? true : ((MODE == MODE_FWD) || (p.wt != 0));
     const int CK = (MODE == MODE_FWD ? p.IA : p.OA) * KK;   // K extent of one component block
 
     if (tid < 8) wptr_s[tid] = p.w.p[tid];
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
         base_w = ow * p.SMw + p.OFFw;
         img_b = dimg * (int)img_elems * 4;
     }
-    const bool strided = (p.SDh > 1) || (p.SDw > 1);
+    const bool strided = FAST ? false : ((p.SDh > 1) || (p.SDw > 1));
     const int srcWb = p.srcW * 4;
     const int base_wb = base_w * 4;
     // row term for tap row 0 (all of it when KH == 1)
@@ -168,10 +172,10 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
             ko = co - kp * p.OA;
         }
     }
-    const bool w_vec = lin && ((CK & 3) == 0);
+    const bool w_vec = FAST ? true : (lin && ((CK & 3) == 0));
 
     float xr[XG][4];
-    float wr[WR][4];
+    float wr[WR][4], wm[WR][4];      // staged weights and their sign / zero multipliers
 
     auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int kk0 = kbeg + chunk * 16;
@@ -213,21 +217,24 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
                 xr[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
             }
         }
-        // W operand: signed gather from the component tensors, k-group = wave
+        // W operand: gather from the component tensors, k-group = wave.  Loads are UNCONDITIONAL (an unused
+        // element reads the component's first word) and the Hamilton sign / zero is kept as a multiplier that is
+        // applied when the registers go to LDS: nothing between the load and the MFMAs waits on memory.
+        typedef const __attribute__((address_space(1))) float* gptr;
         const int kw = kk0 + wave * 4;
         if (lin) {
             if (w_vec) {
                 const bool kin = kw < kend;
 #pragma unroll
                 for (int j = 0; j < WR; ++j) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     bool zero, neg;
                     const int comp = (MODE == MODE_FWD) ? hc_comp(A, w_a[j], kq, &zero, &neg) : hc_comp(A, kq, w_a[j], &zero, &neg);
-                    if (kin && w_ok[j] && !zero) {
-                        v = *reinterpret_cast<const float4*>(wptr_s[comp] + w_off[j] + kl);
-                        if (neg) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
-                    }
-                    wr[j][0] = v.x; wr[j][1] = v.y; wr[j][2] = v.z; wr[j][3] = v.w;
+                    const bool use = kin && w_ok[j] && !zero;
+                    gptr base = (gptr)wptr_s[comp];
+                    const floatx4 v = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(base + (use ? w_off[j] + kl : 0));
+                    wr[j][0] = v[0]; wr[j][1] = v[1]; wr[j][2] = v[2]; wr[j][3] = v[3];
+                    const float m = use ? (neg ? -1.f : 1.f) : 0.f;
+                    wm[j][0] = m; wm[j][1] = m; wm[j][2] = m; wm[j][3] = m;
                 }
             } else {
                 int q = kq, l = kl;
@@ -238,18 +245,20 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
                     for (int j = 0; j < WR; ++j) {
                         bool zero, neg;
                         const int comp = (MODE == MODE_FWD) ? hc_comp(A, w_a[j], q, &zero, &neg) : hc_comp(A, q, w_a[j], &zero, &neg);
-                        float v = 0.f;
-                        if (kin && w_ok[j] && !zero) {
-                            v = wptr_s[comp][w_off[j] + l];
-                            if (neg) v = -v;
-                        }
-                        wr[j][s] = v;
+                        const bool use = kin && w_ok[j] && !zero;
+                        gptr base = (gptr)wptr_s[comp];
+                        wr[j][s] = base[use ? w_off[j] + l : 0];
+                        wm[j][s] = use ? (neg ? -1.f : 1.f) : 0.f;
                     }
                     if (++l >= CK) { l = 0; ++q; }
                 }
             }
             kl += 16;
-            while (kl >= CK) { kl -= CK; ++kq; }
+            if (FAST) {
+                if (kl >= CK) { kl -= CK; ++kq; }          // CK >= 16: at most one wrap, a scalar select
+            } else {
+                while (kl >= CK) { kl -= CK; ++kq; }
+            }
         } else {
             int pp = kp, o = ko, x = kx;
 #pragma unroll
@@ -260,12 +269,10 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
                 for (int j = 0; j < WR; ++j) {
                     bool zero, neg;
                     const int comp = hc_comp(A, pp, w_a[j], &zero, &neg);
-                    float v = 0.f;
-                    if (kin && w_ok[j] && !zero) {
-                        v = wptr_s[comp][soff + w_off[j]];
-                        if (neg) v = -v;
-                    }
-                    wr[j][s] = v;
+                    const bool use = kin && w_ok[j] && !zero;
+                    gptr base = (gptr)wptr_s[comp];
+                    wr[j][s] = base[use ? soff + w_off[j] : 0];
+                    wm[j][s] = use ? (neg ? -1.f : 1.f) : 0.f;
                 }
                 if (++x >= KK) { x = 0; if (++o >= p.OA) { o = 0; ++pp; } }
             }
@@ -285,7 +292,8 @@ __global__ __launch_bounds__(256) void hc_conv_kernel(const ConvP p) {
         for (int j = 0; j < WR; ++j) {
             const int ch = lane + 64 * j;
             if (ch < BC)
-                *reinterpret_cast<float4*>(&Ws[buf][wave][ch][0]) = make_float4(wr[j][0], wr[j][1], wr[j][2], wr[j][3]);
+                *reinterpret_cast<float4*>(&Ws[buf][wave][ch][0]) =
+                    make_float4(wr[j][0] * wm[j][0], wr[j][1] * wm[j][1], wr[j][2] * wm[j][2], wr[j][3] * wm[j][3]);
         }
     };
 
@@ -494,10 +502,14 @@ template <int CT, int PT, int MODE>
 static void launch_conv(const ConvP& p, hipStream_t st) {
     constexpr int BC = CT * 16, BP = PT * 64;
     dim3 grid((unsigned)((p.Ptot + BP - 1) / BP), (unsigned)((p.Cdst + BC - 1) / BC), 1);
-    if (p.KH == 1 && p.KW == 1) hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 1, 1, MODE>), grid, dim3(256), 0, st, p);
-    else if (p.KH == 1 && p.KW == 3) hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 1, 3, MODE>), grid, dim3(256), 0, st, p);
-    else if (p.KH == 3 && p.KW == 3) hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 3, 3, MODE>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 0, 0, MODE>), grid, dim3(256), 0, st, p);
+    const int KK = p.KH * p.KW;
+    const int CK = (MODE == MODE_FWD ? p.IA : p.OA) * KK;
+    const bool fast = (MODE == MODE_FWD || p.wt) && (CK % 4 == 0) && CK >= 16 && p.SDh == 1 && p.SDw == 1 &&
+                      !getenv("SELD_CONV_NOFAST");
+    if (fast && p.KH == 1 && p.KW == 1) hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 1, 1, MODE, 1>), grid, dim3(256), 0, st, p);
+    else if (fast && p.KH == 1 && p.KW == 3) hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 1, 3, MODE, 1>), grid, dim3(256), 0, st, p);
+    else if (fast && p.KH == 3 && p.KW == 3) hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 3, 3, MODE, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 0, 0, MODE, 0>), grid, dim3(256), 0, st, p);
 }
 
 template <int MODE>
@@ -646,6 +658,9 @@ extern "C" int seld_hc_conv_kernel_label(const seld_conv_desc* d, int32_t which,
         }
     }
     const TileCfg c = pick_cfg(which == 0 ? d->Cout : d->Cin, P);
-    snprintf(buf, buflen, "hc_conv_kernel<%d, %d, %d, %d, %d>", c.ct, c.pt, kh, kw, which);
+    const int CKl = ((which == 0 ? d->Cin : d->Cout) / d->algebra) * d->k[0] * d->k[1];
+    const bool fast = (CKl % 4 == 0) && CKl >= 16 && (which == 0 || (d->stride[0] == 1 && d->stride[1] == 1)) && kh != 0 &&
+                      !getenv("SELD_CONV_NOFAST");
+    snprintf(buf, buflen, "hc_conv_kernel<%d, %d, %d, %d, %d, %d>", c.ct, c.pt, fast ? kh : 0, fast ? kw : 0, which, fast ? 1 : 0);
     return SELD_OK;
 }

@@ -286,16 +286,19 @@ __global__ __launch_bounds__(256) void hc_wgrad32_kernel(const WgradP p) {
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.x + (size_t)img_first * x_img), 0, x_remain > 0xFFFFFFFFLL ? 0xFFFFFFFFu : (unsigned)x_remain, 0x00020000);
 
-    float ar[AR][4], br[BR][4];
+    float ar[AR][4], br[BR][4], am[AR];
 
     auto load_chunk = [&](int) __attribute__((always_inline)) {
         const bool pin = t_pos < pend;          // outW % 4 == 0: the group's 4 positions share row and validity
-        const float* dyb = p.dy + (size_t)t_img * dy_img + (size_t)t_oh * p.outW + t_ow;
+        // unconditional 16-byte loads (an inactive item re-reads the tensor's first words); validity is applied as a
+        // 0/1 multiplier when the registers go to LDS, so no branch and no wait sits between loads and MFMAs
+        const float* dyb = pin ? p.dy + (size_t)t_img * dy_img + (size_t)t_oh * p.outW + t_ow : p.dy;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pin && a_ok[j]) v = *reinterpret_cast<const float4*>(dyb + a_off[j]);
+            const bool use = pin && a_ok[j];
+            const float4 v = *reinterpret_cast<const float4*>(dyb + (use ? a_off[j] : 0));
             ar[j][0] = v.x; ar[j][1] = v.y; ar[j][2] = v.z; ar[j][3] = v.w;
+            am[j] = use ? 1.f : 0.f;
         }
         // x gather through a buffer descriptor based at this split's first image: an invalid tap gets the
         // offset 0xFFFFFFFF, which the hardware range check turns into 0.0 (no exec-mask juggling)
@@ -312,19 +315,21 @@ __global__ __launch_bounds__(256) void hc_wgrad32_kernel(const WgradP p) {
                 br[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, 0, 0));
             }
         }
-        // advance by 32 positions
+        // advance by 32 positions (outW >= 32: at most one wrap per level -> selects, no loop)
         t_pos += 32;
         t_ow += 32;
-        while (t_ow >= p.outW) {
-            t_ow -= p.outW;
-            if (++t_oh >= p.outH) { t_oh = 0; ++t_img; }
-        }
+        const bool wrap_w = t_ow >= p.outW;
+        t_ow -= wrap_w ? p.outW : 0;
+        t_oh += wrap_w ? 1 : 0;
+        const bool wrap_h = t_oh >= p.outH;
+        t_oh = wrap_h ? 0 : t_oh;
+        t_img += wrap_h ? 1 : 0;
     };
     auto store_chunk = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             const int r = rsub + 32 * j;
-            if (r < BM) *reinterpret_cast<float4*>(&As[buf][g][r][0]) = make_float4(ar[j][0], ar[j][1], ar[j][2], ar[j][3]);
+            if (r < BM) *reinterpret_cast<float4*>(&As[buf][g][r][0]) = make_float4(ar[j][0] * am[j], ar[j][1] * am[j], ar[j][2] * am[j], ar[j][3] * am[j]);
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
@@ -460,7 +465,7 @@ static int wgrad_cfg(const seld_conv_desc* d) {
 }
 
 static bool wgrad_fast_ok(const WgradP& p) {
-    return (p.outW % 4 == 0) && p.sw == 1 && !getenv("SELD_WGRAD_SLOW");
+    return (p.outW % 4 == 0) && p.outW >= 32 && p.sw == 1 && !getenv("SELD_WGRAD_SLOW");
 }
 
 template <int WRW, int RT, int CTL>
@@ -530,7 +535,7 @@ int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
     const char* t = cfg == 0 ? "2, 4, 4" : (cfg == 1 ? "4, 3, 5" : (cfg == 3 ? "2, 3, 4" : "2, 2, 2"));
     int o[2];
     hc_out_shape(d, o);
-    const bool fast = (o[1] % 4 == 0) && d->stride[1] == 1 && !getenv("SELD_WGRAD_SLOW");
+    const bool fast = (o[1] % 4 == 0) && o[1] >= 32 && d->stride[1] == 1 && !getenv("SELD_WGRAD_SLOW");
     snprintf(buf, buflen, "%s<%s, %d, %d>", fast ? "hc_wgrad32_kernel" : "hc_wgrad_kernel", t, kh, kw);
     return SELD_OK;
 }
