@@ -25,6 +25,8 @@ struct ConvP {
     int skip_mode;             // 0 none, 1 (fwd DQ): low-half channels x high-half K is zero, 2 (dgrad DQ): high x low
     int epilogue;
     WPtrs w;
+    const float* wmin;         // lowest component pointer (hc_conv_vec_kernel addresses the others as 32-bit offsets from it)
+    unsigned wspan;            // bytes from wmin to the end of the highest component tensor
     const float* src;
     const float* bias;
     float* dst;

@@ -498,9 +498,13 @@ __global__ void hc_transpose_w_kernel(WPtrs w, int A, int OA, int IA, int KK, fl
     out[idx] = w.p[comp][((size_t)o * IA + c) * KK + k];
 }
 
+int hc_conv_vec_try(const ConvP& p, int mode, int ct, int pt, hipStream_t st);
+int hc_conv_vec_chunk(const ConvP& p, int mode, int ct, int pt);
+
 template <int CT, int PT, int MODE>
 static void launch_conv(const ConvP& p, hipStream_t st) {
     constexpr int BC = CT * 16, BP = PT * 64;
+    if (hc_conv_vec_try(p, MODE, CT, PT, st)) return;     // loop-invariant staging variant (hc_conv_vec.hip)
     dim3 grid((unsigned)((p.Ptot + BP - 1) / BP), (unsigned)((p.Cdst + BC - 1) / BC), 1);
     const int KK = p.KH * p.KW;
     const int CK = (MODE == MODE_FWD ? p.IA : p.OA) * KK;
@@ -531,7 +535,37 @@ static void fill_common(ConvP& p, const seld_conv_desc* d, const float* const w[
     p.pairing = getenv("SELD_CONV_PAIR") ? 1 : 0;   // measured 5-14 % slower on the TCN layers: off by default
     p.KH = d->k[0]; p.KW = d->k[1];
     p.OA = d->Cout / d->algebra; p.IA = d->Cin / d->algebra;
-    for (int i = 0; i < 8; ++i) p.w.p[i] = (i < d->algebra) ? w[i] : nullptr;
+    for (int i = 0; i < 8; ++i) p.w.p[i] = (w && i < d->algebra) ? w[i] : nullptr;
+}
+
+static void fill_fwd(ConvP& p, const seld_conv_desc* d, const float* const w[8], const int o[2]) {
+    fill_common(p, d, w);
+    p.mode = MODE_FWD;
+    p.Csrc = d->Cin; p.Cdst = d->Cout;
+    p.srcH = d->in[0]; p.srcW = d->in[1]; p.dstH = o[0]; p.dstW = o[1];
+    p.SMh = d->stride[0]; p.OFFh = -d->pad[0]; p.KDh = d->dil[0]; p.SDh = 1;
+    p.SMw = d->stride[1]; p.OFFw = -d->pad[1]; p.KDw = d->dil[1]; p.SDw = 1;
+    p.Ktot = d->Cin * p.KH * p.KW;
+    p.srcS = p.srcH * p.srcW; p.dstS = p.dstH * p.dstW;
+    p.Ptot = (long long)d->N * p.dstS;
+    p.src_elems = (long long)d->N * p.Csrc * p.srcS;
+    p.skip_mode = (d->algebra == 8) ? 1 : 0;
+}
+
+static void fill_dgrad(ConvP& p, const seld_conv_desc* d, const float* const w[8], const int o[2]) {
+    fill_common(p, d, w);
+    p.mode = MODE_DGRAD;
+    p.Csrc = d->Cout; p.Cdst = d->Cin;
+    p.srcH = o[0]; p.srcW = o[1]; p.dstH = d->in[0]; p.dstW = d->in[1];
+    // oh = (ih + pad - kh*dil) / stride
+    p.SMh = 1; p.OFFh = d->pad[0]; p.KDh = -d->dil[0]; p.SDh = d->stride[0];
+    p.SMw = 1; p.OFFw = d->pad[1]; p.KDw = -d->dil[1]; p.SDw = d->stride[1];
+    p.Ktot = d->Cout * p.KH * p.KW;
+    p.srcS = p.srcH * p.srcW; p.dstS = p.dstH * p.dstW;
+    p.Ptot = (long long)d->N * p.dstS;
+    p.src_elems = (long long)d->N * p.Csrc * p.srcS;
+    p.skip_mode = (d->algebra == 8) ? 2 : 0;
+    p.epilogue = 0;
 }
 
 }  // namespace seld
@@ -556,17 +590,7 @@ extern "C" int seld_hc_conv_fwd_ex(const seld_conv_desc* d, const float* x, cons
     if ((epilogue & SELD_EPI_ADD) && !addend) return SELD_EINVAL;
     if ((epilogue & SELD_EPI_STATS) && !stats) return SELD_EINVAL;
     ConvP p{};
-    fill_common(p, d, w);
-    p.mode = MODE_FWD;
-    p.Csrc = d->Cin; p.Cdst = d->Cout;
-    p.srcH = d->in[0]; p.srcW = d->in[1]; p.dstH = o[0]; p.dstW = o[1];
-    p.SMh = d->stride[0]; p.OFFh = -d->pad[0]; p.KDh = d->dil[0]; p.SDh = 1;
-    p.SMw = d->stride[1]; p.OFFw = -d->pad[1]; p.KDw = d->dil[1]; p.SDw = 1;
-    p.Ktot = d->Cin * p.KH * p.KW;
-    p.srcS = p.srcH * p.srcW; p.dstS = p.dstH * p.dstW;
-    p.Ptot = (long long)d->N * p.dstS;
-    p.src_elems = (long long)d->N * p.Csrc * p.srcS;
-    p.skip_mode = (d->algebra == 8) ? 1 : 0;
+    fill_fwd(p, d, w, o);
     p.epilogue = epilogue;
     p.src = x; p.bias = bias; p.dst = y; p.addend = addend; p.stats = stats;
     int rc2 = SELD_OK;
@@ -599,19 +623,7 @@ extern "C" int seld_hc_conv_bwd_data_ex(const seld_conv_desc* d, const float* dy
     if (o[0] <= 0 || o[1] <= 0 || !dy || !w || !dx) return SELD_EINVAL;
     if ((long long)d->Cout * o[0] * o[1] >= (1LL << 28)) return SELD_EUNSUPPORTED;
     ConvP p{};
-    fill_common(p, d, w);
-    p.mode = MODE_DGRAD;
-    p.Csrc = d->Cout; p.Cdst = d->Cin;
-    p.srcH = o[0]; p.srcW = o[1]; p.dstH = d->in[0]; p.dstW = d->in[1];
-    // oh = (ih + pad - kh*dil) / stride
-    p.SMh = 1; p.OFFh = d->pad[0]; p.KDh = -d->dil[0]; p.SDh = d->stride[0];
-    p.SMw = 1; p.OFFw = d->pad[1]; p.KDw = -d->dil[1]; p.SDw = d->stride[1];
-    p.Ktot = d->Cout * p.KH * p.KW;
-    p.srcS = p.srcH * p.srcW; p.dstS = p.dstH * p.dstW;
-    p.Ptot = (long long)d->N * p.dstS;
-    p.src_elems = (long long)d->N * p.Csrc * p.srcS;
-    p.skip_mode = (d->algebra == 8) ? 2 : 0;
-    p.epilogue = 0;
+    fill_dgrad(p, d, w, o);
     p.src = dy; p.bias = nullptr; p.dst = dx;
     const size_t need = seld_hc_conv_bwd_data_workspace(d);
     if (workspace && workspace_bytes >= need) {
@@ -642,13 +654,11 @@ extern "C" int seld_hc_conv_kernel_label(const seld_conv_desc* d, int32_t which,
     if (!((kh == 1 && kw == 1) || (kh == 1 && kw == 3) || (kh == 3 && kw == 3))) kh = kw = 0;
     int o[2];
     hc_out_shape(d, o);
-    const long long P = which == 0 ? (long long)d->N * o[0] * o[1] : (long long)d->N * d->in[0] * d->in[1];
+    ConvP p{};
+    if (which == 0) fill_fwd(p, d, nullptr, o);
+    else { fill_dgrad(p, d, nullptr, o); p.wt = 1; }          // the host mirror always supplies the transposed-weight workspace
+    const long long P = p.Ptot;
     if (which == 0 && d->stride[0] == 1 && d->stride[1] == 1) {
-        ConvP p{};
-        p.mode = MODE_FWD; p.algebra = d->algebra; p.SDh = p.SDw = p.SMh = p.SMw = 1;
-        p.Ktot = d->Cin * d->k[0] * d->k[1]; p.Cdst = d->Cout; p.dstS = o[0] * o[1]; p.Ptot = P;
-        p.src_elems = (long long)d->N * d->Cin * d->in[0] * d->in[1];
-        p.epilogue = 0;
         int dummy;
         const int ct = hc_conv_smallk_try(p, nullptr, &dummy, 1);
         if (ct) {
@@ -658,6 +668,10 @@ extern "C" int seld_hc_conv_kernel_label(const seld_conv_desc* d, int32_t which,
         }
     }
     const TileCfg c = pick_cfg(which == 0 ? d->Cout : d->Cin, P);
+    if (hc_conv_vec_chunk(p, which, c.ct, c.pt)) {
+        snprintf(buf, buflen, "hc_conv_vec_kernel<%d, %d, %d, %d, %d>", c.ct, c.pt, kh, kw, which);
+        return SELD_OK;
+    }
     const int CKl = ((which == 0 ? d->Cin : d->Cout) / d->algebra) * d->k[0] * d->k[1];
     const bool fast = (CKl % 4 == 0) && CKl >= 16 && (which == 0 || (d->stride[0] == 1 && d->stride[1] == 1)) && kh != 0 &&
                       !getenv("SELD_CONV_NOFAST");

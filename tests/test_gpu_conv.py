@@ -86,6 +86,70 @@ def test_conv_random_vs_oracle(algebra, shape, cout, k, pad, dil):
     _close(bd.grad, b64.grad)
 
 
+# Loop-invariant-staging kernel (hc_conv_vec.hip): tile forced with SELD_CONV_CFG so that small problems take it.
+# Cases cover every tap set, all three algebras, the dual-quaternion zero quadrant with a workgroup straddling the
+# primal/dual boundary (12 tiles over 192 channels) and without (6 tiles), edge workgroups (every tile of a 1-image
+# problem) next to interior ones (N >= 3), images shorter than a tile, a ragged last tile, channel counts that do
+# not fill the tile, halo wider than a quad (dilation 5 / 27) and the fused epilogues.
+VEC_CASES = [
+    # algebra, x shape, cout, k, pad, dil, cfg
+    (8, (4, 192, 128), 384, 3, 1, 1, "12,1"),
+    (8, (4, 192, 128), 192, 3, 5, 5, "12,1"),
+    (8, (2, 192, 64), 192, 3, 1, 1, "6,1"),          # an all-primal and an all-dual workgroup
+    (8, (3, 384, 64), 192, 1, 0, 1, "6,1"),
+    (8, (5, 192, 40), 192, 3, 27, 27, "6,1"),        # images shorter than the 64-position tile, ragged tail
+    (8, (3, 192, 8, 32), 192, (3, 3), 1, 1, "12,1"),
+    (8, (2, 96, 6, 16), 32, (3, 3), 1, 1, "6,1"),      # 32 of 96 tile channels used
+    (4, (3, 96, 100), 64, 3, 2, 2, "6,1"),
+    (4, (2, 16, 12, 24), 48, (3, 3), 1, 1, "12,1"),
+    (1, (3, 24, 72), 48, 1, 0, 1, "6,1"),
+    (1, (2, 8, 9, 36), 16, (3, 3), 1, 1, "6,1"),
+    (1, (4, 8, 256), 24, 3, 3, 3, "12,1"),
+]
+
+
+@pytest.mark.parametrize("algebra,shape,cout,k,pad,dil,cfg", VEC_CASES)
+def test_conv_vec_kernel_vs_oracle(algebra, shape, cout, k, pad, dil, cfg, monkeypatch):
+    import seld_amd
+    H = seld_amd.hip_ops
+    monkeypatch.setenv("SELD_CONV_CFG", cfg)
+    kk = (k,) if isinstance(k, int) else k
+    desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
+    assert H._label(desc, 0).startswith("hc_conv_vec_kernel<" + cfg.replace(",", ", ")), H._label(desc, 0)
+    assert H._label(desc, 1).startswith("hc_conv_vec_kernel<" + cfg.replace(",", ", ")), H._label(desc, 1)
+    gen = torch.Generator().manual_seed(4321)
+    x = torch.randn(shape, generator=gen)
+    wshape = (cout // algebra, shape[1] // algebra) + tuple(kk)
+    ws = [torch.randn(wshape, generator=gen) * 0.2 for _ in range(algebra)]
+    bias = torch.randn(cout, generator=gen)
+    dev = torch.device("cuda:0")
+    xd = x.to(dev).requires_grad_(True)
+    wd = [w.to(dev).requires_grad_(True) for w in ws]
+    bd = bias.to(dev).requires_grad_(True)
+    y = H.hyper_conv(xd, wd, bd, 1, pad, dil)
+    cot = torch.randn(y.shape, generator=gen)
+    (y * cot.to(dev)).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    w64 = [w.double() for w in ws]
+    yr = O.hypercomplex_conv(x64, w64, bias.double(), 1, pad, 1, dil, mode="explicit")
+    (yr * cot.double()).sum().backward()
+    _close(y, yr)
+    _close(xd.grad, x64.grad)
+    # fused epilogues on the same kernel: + addend, batch statistics
+    L = seld_amd._lib
+    addend = torch.randn(y.shape, generator=gen).to(dev)
+    stats_rep = H.new_stats(cout, dev)
+    y2 = H.conv_fwd(desc, xd.detach(), [w.detach() for w in wd], bd.detach(),
+                    epilogue=L.SELD_EPI_ADD | L.SELD_EPI_STATS, addend=addend, stats=stats_rep)
+    torch.cuda.synchronize()
+    ref2 = yr.detach() + addend.double().cpu()
+    _close(y2, ref2)
+    stats = stats_rep.view(H.STATS_REPLICAS, 2 * cout).sum(0).double().cpu()
+    red = tuple(i for i in range(ref2.dim()) if i != 1)
+    assert torch.allclose(stats[:cout], ref2.sum(dim=red), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(stats[cout:], (ref2 * ref2).sum(dim=red), rtol=1e-4, atol=2e-3)
+
+
 def test_conv_epilogues():
     import seld_amd
     H = seld_amd.hip_ops
