@@ -49,7 +49,17 @@ struct WgradP {
     const float* x;
     const float* dy;
     WPtrsMut gw;       // component gradients (accumulated into)
+    int mz, nact, nt;  // tile enumeration without the zero quadrant: the first mz row tiles have nact column tiles, the rest nt
+    int dbg;           // SELD_WGRAD_DBG: timing experiments (wrong results): 1 = no loads in the loop, 2 = no LDS stores
 };
+
+// blockIdx.x -> (row tile, column tile), skipping the tiles that lie wholly in the dual-quaternion zero quadrant, so
+// that consecutive workgroup ids (which the dispatcher deals round-robin to the 8 XCDs) all carry work.
+__device__ __forceinline__ void wgrad_tile(const WgradP& p, int* mt, int* nt) {
+    const int t = blockIdx.x, head = p.mz * p.nact;
+    if (t < head) { *mt = t / p.nact; *nt = t - *mt * p.nact; }
+    else { const int u = t - head; const int m = u / p.nt; *mt = p.mz + m; *nt = u - m * p.nt; }
+}
 
 // Block (p, q) of the Hamilton matrix with one index per lane and the other wave-uniform:
 // returns the component, *zero for the structural zero quadrant, *neg for a negative sign.

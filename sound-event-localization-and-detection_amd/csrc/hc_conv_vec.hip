@@ -278,6 +278,9 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
             const int buf = chunk & 1;
             if (comp_switch) setup_comp();
             load_chunk(edgec);
+            // Loads stay at the top of the step, LDS stores at the bottom (left alone, the scheduler sinks the loads
+            // to the middle of the MFMA stream and they get ~40 MFMAs to land before the stores wait on them).
+            __builtin_amdgcn_sched_barrier(0);
             const float* xb = &Xs[buf][0][wave * (PT * 16) + fr];
 #pragma unroll
             for (int r = 0; r < NS; ++r) {
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
                     for (int i = 0; i < PT; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][1], bv[j].y, acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             store_chunk(buf ^ 1);
             __syncthreads();
         }

@@ -27,8 +27,10 @@ __global__ __launch_bounds__(256) void hc_wgrad_kernel(const WgradP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr_ = wave / WCW, wc_ = wave % WCW;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    int tile_m, tile_n;
+    wgrad_tile(p, &tile_m, &tile_n);
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
     const int split = blockIdx.z;
     const int KH = KH_T ? KH_T : p.KH;
     const int KW = KW_T ? KW_T : p.KW;
@@ -221,14 +223,17 @@ __global__ __launch_bounds__(256) void hc_wgrad32_kernel(const WgradP p) {
     constexpr int BN = WCW * CTL * 16;
     constexpr int AR = (BM + 31) / 32;       // rows staged per thread (32 rows per pass)
     constexpr int BR = (BN + 31) / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][8][BM][4];   // dy   [k-group][co][4 positions]
-    __shared__ __attribute__((aligned(16))) float Bs[2][8][BN][4];   // xcol [k-group][col][4 positions]
+    // row pitch = 2 (mod 16) float4: the 8 position groups of a store then hit different LDS banks
+    __shared__ __attribute__((aligned(16))) float As[2][8][(BM + 15) / 16 * 16 + 2][4];   // dy   [k-group][co][4 positions]
+    __shared__ __attribute__((aligned(16))) float Bs[2][8][(BN + 15) / 16 * 16 + 2][4];   // xcol [k-group][col][4 positions]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr_ = wave / WCW, wc_ = wave % WCW;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    int tile_m, tile_n;
+    wgrad_tile(p, &tile_m, &tile_n);
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
     const int split = blockIdx.z;
     const int KH = KH_T ? KH_T : p.KH;
     const int KW = KW_T ? KW_T : p.KW;
@@ -425,21 +430,34 @@ __global__ void zero_many_kernel(const ZeroP z) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = 0.f;
 }
 
-static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, long long* split_len) {
-    long long Ptot = (long long)d->N * o[0] * o[1];
-    long long Ktot = (long long)d->Cin * d->k[0] * d->k[1];
-    long long tiles = ((d->Cout + bm - 1) / bm) * ((Ktot + bn - 1) / bn);
-    if (d->algebra == 8) tiles = tiles * 3 / 4 > 0 ? tiles * 3 / 4 : 1;   // zero-quadrant tiles exit at once
-    long long target = 768;                               // ~3 workgroups per CU
-    if (const char* e = getenv("SELD_WGRAD_WGS")) target = atoll(e) > 0 ? atoll(e) : target;
-    long long want = (target + tiles - 1) / tiles;
-    long long maxs = (Ptot + 511) / 512;                  // at least 512 positions per split
+// Number of position splits.  The kernels keep 2 workgroups per CU resident (4 for the 64 x 64 tile): a launch
+// of W workgroups runs in ceil(W / slots) generations of equal length, so the split count is the LARGEST one whose
+// active workgroups (tiles outside the dual-quaternion zero quadrant) still fit in one generation -- 21 tiles x 25
+// splits = 525 workgroups on 512 slots take twice as long as 21 x 24 (measured: 2088 vs 1422 us on the 3x3 layer).
+// Short reductions are split less (at least 512 positions per workgroup) and then run several generations deep.
+static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, WgradP* p) {
+    long long* split_len = &p->split_len;
+    const long long Ptot = (long long)d->N * o[0] * o[1];
+    const long long Ktot = (long long)d->Cin * d->k[0] * d->k[1];
+    const long long mt = (d->Cout + bm - 1) / bm, nt = (Ktot + bn - 1) / bn;
+    long long tiles = mt * nt;
+    p->mz = 0; p->nact = (int)nt; p->nt = (int)nt;
+    if (d->algebra == 8) {
+        // tiles that lie wholly in the zero quadrant (rows < Cout/2, columns >= Ktot/2) are not launched
+        const long long mz = (d->Cout / 2) / bm;                       // row tiles entirely primal
+        const long long nz = nt - ((Ktot / 2) + bn - 1) / bn;          // column tiles entirely in the upper K half
+        if (nz > 0 && mz > 0) { p->mz = (int)mz; p->nact = (int)(nt - nz); tiles -= mz * nz; }
+    }
+    long long slots = (bm == 64 ? 4 : 2) * 256;
+    if (const char* e = getenv("SELD_WGRAD_WGS")) slots = atoll(e) > 0 ? atoll(e) : slots;
+    long long want = slots / tiles;                       // floor: stay within one generation
+    const long long maxs = (Ptot + 511) / 512;            // at least 512 positions per split
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     if (want > 1024) want = 1024;
     long long len = (Ptot + want - 1) / want;
     len = (len + 31) / 32 * 32;
-    int ns = (int)((Ptot + len - 1) / len);
+    const int ns = (int)((Ptot + len - 1) / len);
     *split_len = len;
     return ns < 1 ? 1 : ns;
 }
@@ -464,6 +482,9 @@ static int wgrad_cfg(const seld_conv_desc* d) {
     return 0;
 }
 
+bool hc_wgrad_row_ok(const WgradP& p);
+void hc_wgrad_row_launch(const WgradP& p, int cfg, hipStream_t st);
+
 static bool wgrad_fast_ok(const WgradP& p) {
     return (p.outW % 4 == 0) && p.outW >= 32 && p.sw == 1 && !getenv("SELD_WGRAD_SLOW");
 }
@@ -471,7 +492,7 @@ static bool wgrad_fast_ok(const WgradP& p) {
 template <int WRW, int RT, int CTL>
 static void launch_wgrad(const WgradP& p, hipStream_t st) {
     constexpr int BM = WRW * RT * 16, BN = (4 / WRW) * CTL * 16;
-    dim3 grid((p.Ktot + BN - 1) / BN, (p.Cout + BM - 1) / BM, p.nsplit);
+    dim3 grid(p.mz * p.nact + ((p.Cout + BM - 1) / BM - p.mz) * p.nt, 1, p.nsplit);
     const bool fast = wgrad_fast_ok(p);
 #define SELD_WG(KH_, KW_)                                                                                         \
     do {                                                                                                          \
@@ -515,10 +536,13 @@ static int wgrad_run(const seld_conv_desc* d, const float* x, const float* dy, f
         if (rc) return rc;
     }
     const int cfg = wgrad_cfg(d);
-    if (cfg == 0) { p.nsplit = wgrad_splits(d, o, 128, 128, &p.split_len); launch_wgrad<2, 4, 4>(p, st); }
-    else if (cfg == 1) { p.nsplit = wgrad_splits(d, o, 192, 80, &p.split_len); launch_wgrad<4, 3, 5>(p, st); }
-    else if (cfg == 3) { p.nsplit = wgrad_splits(d, o, 96, 128, &p.split_len); launch_wgrad<2, 3, 4>(p, st); }
-    else { p.nsplit = wgrad_splits(d, o, 64, 64, &p.split_len); launch_wgrad<2, 2, 2>(p, st); }
+    static const int tile_m[4] = {128, 192, 64, 96}, tile_n[4] = {128, 80, 64, 128};
+    p.nsplit = wgrad_splits(d, o, tile_m[cfg], tile_n[cfg], &p);
+    if (hc_wgrad_row_ok(p)) hc_wgrad_row_launch(p, cfg, st);           // row-chunk staging (hc_wgrad_row.hip)
+    else if (cfg == 0) launch_wgrad<2, 4, 4>(p, st);
+    else if (cfg == 1) launch_wgrad<4, 3, 5>(p, st);
+    else if (cfg == 3) launch_wgrad<2, 3, 4>(p, st);
+    else launch_wgrad<2, 2, 2>(p, st);
     rc = check_launch();
     if (rc) return rc;
     if (dbias) {
@@ -536,7 +560,11 @@ int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
     int o[2];
     hc_out_shape(d, o);
     const bool fast = (o[1] % 4 == 0) && o[1] >= 32 && d->stride[1] == 1 && !getenv("SELD_WGRAD_SLOW");
-    snprintf(buf, buflen, "%s<%s, %d, %d>", fast ? "hc_wgrad32_kernel" : "hc_wgrad_kernel", t, kh, kw);
+    WgradP p{};
+    p.KH = d->k[0]; p.KW = d->k[1]; p.sw = d->stride[1]; p.outW = o[1]; p.split_len = 32;
+    p.Cout = d->Cout; p.Cin = d->Cin; p.outS = o[0] * o[1]; p.inS = d->in[0] * d->in[1];
+    const bool row = hc_wgrad_row_ok(p);
+    snprintf(buf, buflen, "%s<%s, %d, %d>", row ? "hc_wgrad_row_kernel" : (fast ? "hc_wgrad32_kernel" : "hc_wgrad_kernel"), t, kh, kw);
     return SELD_OK;
 }
 
