@@ -142,6 +142,14 @@ int seld_bn_finalize(const float* stats, int32_t C, int64_t count, float eps, fl
                      float* mean, float* invstd, float* running_mean /* nullable */,
                      float* running_var /* nullable */, void* stream);
 
+/* same, plus the rest of torch.nn.BatchNorm's train-mode bookkeeping in the one launch: *num_batches_tracked += 1
+ * (nullable; `_BatchNorm.forward` does it as a separate op) and, if clear_stats != 0, the stats buffer is left
+ * zero-filled so that the caller can reuse it without another fill. */
+int seld_bn_finalize_ex(float* stats, int32_t C, int64_t count, float eps, float momentum,
+                        float* mean, float* invstd, float* running_mean /* nullable */,
+                        float* running_var /* nullable */, int64_t* num_batches_tracked /* nullable */,
+                        int32_t clear_stats, void* stream);
+
 /* eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps) */
 int seld_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
                        float* mean, float* invstd, void* stream);

@@ -86,15 +86,21 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
     block_atomic<2>(v, dst);
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double count, float eps, float momentum,
+__global__ void bn_finalize_kernel(float* __restrict__ stats, int C, double count, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ rmean, float* __restrict__ rvar) {
+                                   float* __restrict__ rmean, float* __restrict__ rvar,
+                                   long long* __restrict__ nbt, int clear) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;                          // num_batches_tracked (torch.nn.BatchNorm bookkeeping)
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
     for (int r = 0; r < SELD_STATS_REPLICAS; ++r) {
         s1 += (double)stats[(size_t)r * 2 * C + c];
         s2 += (double)stats[(size_t)r * 2 * C + C + c];
+        if (clear) {                                       // hand the buffer back zeroed (pooled by the host mirror)
+            stats[(size_t)r * 2 * C + c] = 0.f;
+            stats[(size_t)r * 2 * C + C + c] = 0.f;
+        }
     }
     const double m = s1 / count;
     double var = s2 / count - m * m;
@@ -506,12 +512,19 @@ extern "C" int seld_channel_stats(const float* x, int32_t N, int32_t C, int32_t 
     return check_launch();
 }
 
-extern "C" int seld_bn_finalize(const float* stats, int32_t C, int64_t count, float eps, float momentum, float* mean,
-                                float* invstd, float* running_mean, float* running_var, void* stream) {
+extern "C" int seld_bn_finalize_ex(float* stats, int32_t C, int64_t count, float eps, float momentum, float* mean,
+                                   float* invstd, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, int32_t clear_stats, void* stream) {
     if (!stats || !mean || !invstd || C <= 0 || count <= 0) return SELD_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), stats, C, (double)count, eps,
-                       momentum, mean, invstd, running_mean, running_var);
+                       momentum, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, clear_stats);
     return check_launch();
+}
+
+extern "C" int seld_bn_finalize(const float* stats, int32_t C, int64_t count, float eps, float momentum, float* mean,
+                                float* invstd, float* running_mean, float* running_var, void* stream) {
+    return seld_bn_finalize_ex(const_cast<float*>(stats), C, count, eps, momentum, mean, invstd, running_mean,
+                               running_var, nullptr, 0, stream);
 }
 
 extern "C" int seld_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,

@@ -268,9 +268,19 @@ def _ncs(x):
 STATS_REPLICAS = 64      # SELD_STATS_REPLICAS
 
 
+_stats_pool = {}     # (C, device) -> zero-filled statistics buffers ready for reuse
+
+
 def new_stats(C, device):
-    """Zeroed BatchNorm statistics buffer: SELD_STATS_REPLICAS rows of [sum(C) | sum of squares(C)]."""
-    return torch.zeros(STATS_REPLICAS * 2 * C, device=device, dtype=torch.float32)
+    """Zeroed BatchNorm statistics buffer: SELD_STATS_REPLICAS rows of [sum(C) | sum of squares(C)].  Buffers are
+    pooled: `bn_prepare` hands one back after `seld_bn_finalize_ex` has consumed AND re-zeroed it, so a training step
+    does not launch a fill per BatchNorm."""
+    free = _stats_pool.get((C, device))
+    if free:
+        return free.pop()
+    t = torch.zeros(STATS_REPLICAS * 2 * C, device=device, dtype=torch.float32)
+    t._seld_pooled = True
+    return t
 
 
 def channel_stats(x):
@@ -280,44 +290,85 @@ def channel_stats(x):
     return stats
 
 
-def bn_prepare(x, running_mean, running_var, training, momentum, eps, stats=None):
-    """mean / invstd used by the normalisation; updates the running buffers in training mode."""
+def bn_prepare(x, running_mean, running_var, training, momentum, eps, stats=None, num_batches_tracked=None):
+    """mean / invstd used by the normalisation; in training mode also the running-buffer update and the
+    num_batches_tracked increment of torch.nn.BatchNorm, all in one launch."""
     N, C, S = _ncs(x)
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
     invstd = torch.empty(C, device=x.device, dtype=torch.float32)
     if training:
         if stats is None:
             stats = channel_stats(x)
-        L.check(L.lib().seld_bn_finalize(L.ptr(stats), C, ctypes.c_int64(N * S), ctypes.c_float(eps),
-                                         ctypes.c_float(momentum), L.ptr(mean), L.ptr(invstd), L.ptr(running_mean),
-                                         L.ptr(running_var), L.current_stream()), "seld_bn_finalize")
+        pooled = getattr(stats, "_seld_pooled", False)
+        L.check(L.lib().seld_bn_finalize_ex(L.ptr(stats), C, ctypes.c_int64(N * S), ctypes.c_float(eps),
+                                            ctypes.c_float(momentum), L.ptr(mean), L.ptr(invstd), L.ptr(running_mean),
+                                            L.ptr(running_var), L.ptr(num_batches_tracked), int(pooled),
+                                            L.current_stream()), "seld_bn_finalize_ex")
+        if pooled:
+            _stats_pool.setdefault((C, x.device), []).append(stats)
     else:
         L.check(L.lib().seld_bn_eval_stats(L.ptr(running_mean), L.ptr(running_var), C, ctypes.c_float(eps),
                                            L.ptr(mean), L.ptr(invstd), L.current_stream()), "seld_bn_eval_stats")
     return mean, invstd
 
 
+def _nbt(bn):
+    """The module's num_batches_tracked buffer when torch.nn.BatchNorm would increment it, else None."""
+    if bn.training and getattr(bn, "track_running_stats", True) and bn.num_batches_tracked is not None:
+        return bn.num_batches_tracked
+    return None
+
+
+def _claim_grad_slots(params, adjacent=True):
+    """Gradient slots of `params` as reduction targets.  Returns (first_slot, clean):
+    first_slot -- `.grad` of the first parameter when every parameter opted in (`_seld_direct_grad`, FlatAdam) and,
+                  if `adjacent`, the slots follow one another in the flat gradient buffer in this order; else None;
+    clean      -- nothing has been written to the slots since the owner's last zero_grad(): the backward kernels may
+                  then use the slots themselves as their (zero-initialised) output / reduction buffers.
+    Marks the slots written."""
+    ts = list(params)
+    if not all(getattr(t, "_seld_direct_grad", False) and t.grad is not None for t in ts):
+        return None, False
+    if adjacent:
+        at = ts[0].grad.data_ptr()
+        for t in ts:
+            if t.grad.data_ptr() != at:
+                return None, False
+            at += 4 * t.numel()
+    owner = getattr(ts[0], "_seld_owner", None)
+    gen = owner.grad_generation if owner is not None else None
+    clean = gen is not None and all(getattr(t, "_seld_owner", None) is owner and
+                                    getattr(t, "_seld_written", None) != gen for t in ts)
+    for t in ts:
+        t._seld_written = gen
+    return ts[0].grad, clean
+
+
 class BnActFn(torch.autograd.Function):
     """y = act(BatchNorm(x)); torch.nn.BatchNorm1d/2d + ReLU/Tanh of model.py:114-116, 279-280."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, stats):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, stats, nbt):
         x = _req(x, "x")
         N, C, S = _ncs(x)
-        mean, invstd = bn_prepare(x, running_mean, running_var, training, momentum, eps, stats)
+        mean, invstd = bn_prepare(x, running_mean, running_var, training, momentum, eps, stats, nbt)
         y = torch.empty_like(x)
         L.check(L.lib().seld_bn_act_fwd(L.ptr(x), N, C, S, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta),
                                         act, L.ptr(y), L.current_stream()), "seld_bn_act_fwd")
         ctx.training, ctx.act = training, act
-        ctx.save_for_backward(x, y, mean, invstd, gamma, beta)
+        ctx.bn_params = (gamma, beta)
+        ctx.save_for_backward(x, y, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, invstd, gamma, beta = ctx.saved_tensors
+        x, y, mean, invstd = ctx.saved_tensors
+        gamma, beta = ctx.bn_params
         dy = _req(dy, "dy")
         N, C, S = _ncs(x)
-        red = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+        slot, clean = _claim_grad_slots((gamma, beta))
+        # [dgamma | dbeta]: reduced straight into the (still zero) flat-gradient slots when possible
+        red = slot if clean else torch.zeros(2 * C, device=x.device, dtype=torch.float32)
         st = L.current_stream()
         L.check(L.lib().seld_bn_act_bwd_reduce(L.ptr(dy), L.ptr(x), L.ptr(y), N, C, S, L.ptr(mean), L.ptr(invstd),
                                                L.ptr(gamma), L.ptr(beta), ctx.act, L.ptr(red), st),
@@ -328,42 +379,48 @@ class BnActFn(torch.autograd.Function):
             L.check(L.lib().seld_bn_act_bwd_apply(L.ptr(dy), L.ptr(x), L.ptr(y), N, C, S, L.ptr(mean), L.ptr(invstd),
                                                   L.ptr(gamma), L.ptr(beta), ctx.act, L.ptr(red), int(ctx.training),
                                                   L.ptr(dx), st), "seld_bn_act_bwd_apply")
-        return dx, red[:C], red[C:], None, None, None, None, None, None, None
+        if slot is not None:
+            if not clean:
+                axpy_(slot, red, 2 * C)
+            return dx, None, None, None, None, None, None, None, None, None, None
+        return dx, red[:C], red[C:], None, None, None, None, None, None, None, None
 
 
 def bn_act(x, bn, act, stats=None):
     """`bn` is a torch.nn.BatchNorm*-shaped module (weight, bias, running_mean, running_var, ...)."""
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
     return BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
-                         bn.momentum if bn.momentum is not None else 0.1, bn.eps, act, stats)
+                         bn.momentum if bn.momentum is not None else 0.1, bn.eps, act, stats, _nbt(bn))
 
 
 class GateFn(torch.autograd.Function):
     """y = tanh(BN_f(yf)) * sigmoid(BN_g(yg)) * channel_mask  (model.py:121-128)."""
 
     @staticmethod
-    def forward(ctx, yf, yg, gf, bf, rmf, rvf, gg, bg, rmg, rvg, training, momentum, eps, mask):
+    def forward(ctx, yf, yg, gf, bf, rmf, rvf, gg, bg, rmg, rvg, training, momentum, eps, mask, nbt_f, nbt_g):
         yf, yg = _req(yf, "yf"), _req(yg, "yg")
         N, C, S = _ncs(yf)
-        mf, isf = bn_prepare(yf, rmf, rvf, training, momentum, eps)
-        mg, isg = bn_prepare(yg, rmg, rvg, training, momentum, eps)
+        mf, isf = bn_prepare(yf, rmf, rvf, training, momentum, eps, None, nbt_f)
+        mg, isg = bn_prepare(yg, rmg, rvg, training, momentum, eps, None, nbt_g)
         y = torch.empty_like(yf)
         L.check(L.lib().seld_gate_fwd(L.ptr(yf), L.ptr(yg), N, C, S, L.ptr(mf), L.ptr(isf), L.ptr(gf), L.ptr(bf),
                                       L.ptr(mg), L.ptr(isg), L.ptr(gg), L.ptr(bg), L.ptr(mask), L.ptr(y),
                                       L.current_stream()), "seld_gate_fwd")
         ctx.training = training
         ctx.has_mask = mask is not None
-        ctx.save_for_backward(yf, yg, mf, isf, gf, bf, mg, isg, gg, bg, *([mask] if mask is not None else []))
+        ctx.bn_params = (gf, bf, gg, bg)
+        ctx.save_for_backward(yf, yg, mf, isf, mg, isg, *([mask] if mask is not None else []))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        yf, yg, mf, isf, gf, bf, mg, isg, gg, bg, *rest = ctx.saved_tensors
+        yf, yg, mf, isf, mg, isg, *rest = ctx.saved_tensors
+        gf, bf, gg, bg = ctx.bn_params
         mask = rest[0] if ctx.has_mask else None
         dy = _req(dy, "dy")
         N, C, S = _ncs(yf)
-        red = torch.zeros(4 * C, device=yf.device, dtype=torch.float32)
+        slot, clean = _claim_grad_slots((gf, bf, gg, bg))
+        # [dgamma_f | dbeta_f | dgamma_g | dbeta_g]
+        red = slot if clean else torch.zeros(4 * C, device=yf.device, dtype=torch.float32)
         st = L.current_stream()
         args = (L.ptr(dy), L.ptr(yf), L.ptr(yg), N, C, S, L.ptr(mf), L.ptr(isf), L.ptr(gf), L.ptr(bf),
                 L.ptr(mg), L.ptr(isg), L.ptr(gg), L.ptr(bg), L.ptr(mask))
@@ -371,17 +428,18 @@ class GateFn(torch.autograd.Function):
         dyf, dyg = torch.empty_like(yf), torch.empty_like(yg)
         L.check(L.lib().seld_gate_bwd_apply(*args, L.ptr(red), int(ctx.training), L.ptr(dyf), L.ptr(dyg), st),
                 "seld_gate_bwd_apply")
+        if slot is not None:
+            if not clean:
+                axpy_(slot, red, 4 * C)
+            return (dyf, dyg) + (None,) * 14
         return (dyf, dyg, red[:C], red[C:2 * C], None, None, red[2 * C:3 * C], red[3 * C:], None, None,
-                None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def gate(yf, yg, bn_f, bn_g, mask=None):
-    for bn in (bn_f, bn_g):
-        if bn.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
     return GateFn.apply(yf, yg, bn_f.weight, bn_f.bias, bn_f.running_mean, bn_f.running_var,
                         bn_g.weight, bn_g.bias, bn_g.running_mean, bn_g.running_var, bn_f.training,
-                        bn_f.momentum if bn_f.momentum is not None else 0.1, bn_f.eps, mask)
+                        bn_f.momentum if bn_f.momentum is not None else 0.1, bn_f.eps, mask, _nbt(bn_f), _nbt(bn_g))
 
 
 # ======================================================================================
@@ -564,6 +622,7 @@ class HyperLinearFn(torch.autograd.Function):
             out_f = ws[0].shape[0]
         else:
             out_f = ws[0].shape[1] * kind
+        ctx.params = (bias, tuple(ws))
         ws = [_req(w, "w") for w in ws]
         y = torch.empty((rows, out_f), device=x.device, dtype=torch.float32)
         L.check(L.lib().seld_hc_linear_fwd(kind, rows, in_f, out_f, L.ptr(x2), L.ptr_array8(ws), L.ptr(_req(bias, "bias")),
@@ -576,18 +635,32 @@ class HyperLinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         kind, rows, in_f, out_f, xshape, has_bias = ctx.meta
         x2, *ws = ctx.saved_tensors
+        bias_p, ws_p = ctx.params
         dy2 = _req(dy.reshape(rows, out_f), "dy")
         dev = dy2.device
         dx = torch.empty((rows, in_f), device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         need_w = any(ctx.needs_input_grad[3:])
-        dws = [torch.empty_like(w) for w in ws] if need_w else None
-        dbias = torch.empty(out_f, device=dev, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[1]) else None
+        need_b = has_bias and ctx.needs_input_grad[1]
+        # The kernel WRITES the parameter gradients: it may write them straight into flat-gradient slots that are
+        # still zero (first and only use of the layer since zero_grad); otherwise autograd accumulates.
+        direct = False
+        if need_w and (need_b or not has_bias) and all(w.is_contiguous() for w in ws_p):
+            slot, clean = _claim_grad_slots(list(ws_p) + ([bias_p] if has_bias else []), adjacent=False)
+            direct = slot is not None and clean
+        if direct:
+            dws, dbias = [w.grad for w in ws_p], (bias_p.grad if has_bias else None)
+        else:
+            dws = [torch.empty_like(w) for w in ws] if need_w else None
+            dbias = torch.empty(out_f, device=dev, dtype=torch.float32) if need_b else None
         nbytes = L.lib().seld_hc_linear_bwd_workspace(kind, in_f, out_f)
         wsb = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
         L.check(L.lib().seld_hc_linear_bwd(kind, rows, in_f, out_f, L.ptr(x2), L.ptr(dy2), L.ptr_array8(ws), L.ptr(dx),
                                            L.ptr_array8(dws) if dws is not None else None, L.ptr(dbias), L.ptr(wsb),
                                            ctypes.c_size_t(nbytes), L.current_stream()), "seld_hc_linear_bwd")
-        return (dx.reshape(xshape) if dx is not None else None, dbias, None, *(dws if dws is not None else [None] * len(ws)))
+        dxr = dx.reshape(xshape) if dx is not None else None
+        if direct:
+            return (dxr, None, None, *([None] * len(ws)))
+        return (dxr, dbias, None, *(dws if dws is not None else [None] * len(ws)))
 
 
 def hyper_linear(x, ws, bias, kind):
@@ -696,10 +769,7 @@ def gate_plain(yf, yg, mask=None):
         _identity_cache[key] = (torch.zeros(C, device=yf.device), torch.ones(C, device=yf.device))
     zero, one = _identity_cache[key]
 
-    class _Id:
-        weight, bias, running_mean, running_var = one, zero, zero, one
-        training, momentum, eps, num_batches_tracked = False, 0.1, 0.0, None
-    return GateFn.apply(yf, yg, one, zero, zero, one, one, zero, zero, one, False, 0.1, 0.0, mask)
+    return GateFn.apply(yf, yg, one, zero, zero, one, one, zero, zero, one, False, 0.1, 0.0, mask, None, None)
 
 
 # ======================================================================================
@@ -738,10 +808,10 @@ class BnReluPoolFn(torch.autograd.Function):
     """MaxPool2d(ph, pw)(ReLU(BatchNorm2d(y))) in one pass each way (model.py:278-281)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, ph, pw, stats):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, ph, pw, stats, nbt):
         y = _req(y, "y")
         N, C, Hh, Ww = y.shape
-        mean, invstd = bn_prepare(y, running_mean, running_var, training, momentum, eps, stats)
+        mean, invstd = bn_prepare(y, running_mean, running_var, training, momentum, eps, stats, nbt)
         pooled = torch.empty((N, C, Hh // ph, Ww // pw), device=y.device, dtype=torch.float32)
         idx = torch.empty(pooled.shape, device=y.device, dtype=torch.uint8)
         L.check(L.lib().seld_bn_relu_pool_fwd(L.ptr(y), N, C, Hh, Ww, ph, pw, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
@@ -758,18 +828,17 @@ class BnReluPoolFn(torch.autograd.Function):
         gamma, beta = ctx.bn_params
         N, C, Hh, Ww, ph, pw, training = ctx.geom
         dpooled = _req(dpooled, "dpooled")
-        direct = _direct_targets((gamma, beta), None)
-        adjacent = direct is not None and gamma.grad.data_ptr() + 4 * C == beta.grad.data_ptr()
-        red = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
+        slot, clean = _claim_grad_slots((gamma, beta))
+        red = slot if clean else torch.zeros(2 * C, device=y.device, dtype=torch.float32)
         dy = torch.empty_like(y)
         L.check(L.lib().seld_bn_relu_pool_bwd(L.ptr(dpooled), L.ptr(pooled), L.ptr(idx), L.ptr(y), N, C, Hh, Ww, ph, pw,
                                               L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(training),
                                               L.ptr(red), L.ptr(dy), L.current_stream()), "seld_bn_relu_pool_bwd")
-        if adjacent:
-            # one add into the flat gradient slice [dgamma | dbeta] instead of two autograd accumulations
-            axpy_(gamma.grad, red, 2 * C)
-            return dy, None, None, None, None, None, None, None, None, None, None
-        return dy, red[:C], red[C:], None, None, None, None, None, None, None, None
+        if slot is not None:
+            if not clean:
+                axpy_(slot, red, 2 * C)     # one add into the flat gradient slice [dgamma | dbeta]
+            return (dy,) + (None,) * 11
+        return (dy, red[:C], red[C:]) + (None,) * 9
 
 
 def axpy_(dst_first, src, n):
@@ -778,7 +847,5 @@ def axpy_(dst_first, src, n):
 
 
 def bn_relu_pool(y, bn, ph, pw, stats=None):
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
     return BnReluPoolFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
-                              bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(ph), int(pw), stats)
+                              bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(ph), int(pw), stats, _nbt(bn))

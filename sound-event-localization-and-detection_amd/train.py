@@ -82,12 +82,15 @@ class FlatAdam:
                 p.data = self.flat_param[off:off + n].view(p.shape)
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
                 p._seld_direct_grad = True      # HIP backward kernels accumulate straight into this view
+                p._seld_owner = self            # ... and may reduce into a slot that is still zero (grad_generation)
                 off += n
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=self.params)]
         self.step_count = 0
+        self.grad_generation = 0
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
+        self.grad_generation += 1       # every slot is zero again (hip_ops._claim_grad_slots)
         off = 0
         for p in self.params:           # re-attach views if something replaced .grad
             n = p.numel()
