@@ -278,61 +278,74 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
             const int buf = chunk & 1;
             if (comp_switch) setup_comp();
             load_chunk(edgec);
-            // Loads stay at the top of the step, LDS stores at the bottom (left alone, the scheduler sinks the loads
-            // to the middle of the MFMA stream and they get ~40 MFMAs to land before the stores wait on them).
-            __builtin_amdgcn_sched_barrier(0);
+            // The MFMA stream is software-pipelined by hand, one scheduling region per stage (sched_barrier): the
+            // fragments of stage r+1 are read from LDS while the MFMAs of stage r run.  Left to itself the scheduler
+            // reads both super groups up front (a long wait before the first MFMA), has no registers left to
+            // prefetch the left-over group (one exposed LDS round trip per two MFMAs at the end), sinks the global
+            // loads into the middle of the stream and hoists the LDS stores -- measured 10-15 %.
             const float* xb = &Xs[buf][0][wave * (PT * 16) + fr];
-#pragma unroll
-            for (int r = 0; r < NS; ++r) {
-                float av[PT][4];
-                floatx4 bv[CT];
+            float av[2][PT][4];
+            floatx4 bv[2][CT];
+            float lav[PT][2];            // left-over stage: NL == 1 uses [0], NL == 2 both
+            float2 lbv[CT];
+            auto read_super = [&](int r, int slot) __attribute__((always_inline)) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int i = 0; i < PT; ++i) av[i][s] = xb[(16 * r + 4 * fk + s) * XROW + i * 16];
+                    for (int i = 0; i < PT; ++i) av[slot][i][s] = xb[(16 * r + 4 * fk + s) * XROW + i * 16];
 #pragma unroll
-                for (int j = J0; j < J1; ++j) bv[j] = *reinterpret_cast<const floatx4*>(&Ws[buf][j * 16 + fr][4 * r + fk][0]);
+                for (int j = J0; j < J1; ++j) bv[slot][j] = *reinterpret_cast<const floatx4*>(&Ws[buf][j * 16 + fr][4 * r + fk][0]);
+            };
+            auto read_left = [&]() __attribute__((always_inline)) {
+                if (NL == 1) {
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) lav[i][0] = xb[(16 * NS + fk) * XROW + i * 16];
+#pragma unroll
+                    for (int j = J0; j < J1; ++j) lbv[j].x = Ws[buf][j * 16 + fr][4 * NS][fk];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int i = 0; i < PT; ++i) lav[i][t] = xb[(16 * NS + 2 * fk + t) * XROW + i * 16];
+#pragma unroll
+                    for (int j = J0; j < J1; ++j)
+                        lbv[j] = *reinterpret_cast<const float2*>(&Ws[buf][j * 16 + fr][4 * NS + (fk >> 1)][(fk & 1) * 2]);
+                }
+            };
+            read_super(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < NS; ++r) {
+                if (r + 1 < NS) read_super(r + 1, (r + 1) & 1);
+                else read_left();
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int j = J0; j < J1; ++j)
 #pragma unroll
                         for (int i = 0; i < PT; ++i)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r & 1][i][s], bv[r & 1][j][s], acc[i][j], 0, 0, 0);
+                // inside the region: one LDS read of the next stage after every second MFMA, from the start
+#pragma unroll
+                for (int q = 0; q < (J1 - J0) + 4 * PT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (NL == 1) {
-                float av[PT], bv[CT];
+            // last region: the left-over MFMAs mix with the register -> LDS stores of the next chunk
 #pragma unroll
-                for (int i = 0; i < PT; ++i) av[i] = xb[(16 * NS + fk) * XROW + i * 16];
+            for (int j = J0; j < J1; ++j)
 #pragma unroll
-                for (int j = J0; j < J1; ++j) bv[j] = Ws[buf][j * 16 + fr][4 * NS][fk];
-#pragma unroll
-                for (int j = J0; j < J1; ++j)
-#pragma unroll
-                    for (int i = 0; i < PT; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-            } else {
-                float av[PT][2];
-                float2 bv[CT];
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int i = 0; i < PT; ++i) av[i][t] = xb[(16 * NS + 2 * fk + t) * XROW + i * 16];
-#pragma unroll
-                for (int j = J0; j < J1; ++j)
-                    bv[j] = *reinterpret_cast<const float2*>(&Ws[buf][j * 16 + fr][4 * NS + (fk >> 1)][(fk & 1) * 2]);
+                for (int i = 0; i < PT; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(lav[i][0], lbv[j].x, acc[i][j], 0, 0, 0);
+            if (NL == 2) {
 #pragma unroll
                 for (int j = J0; j < J1; ++j)
 #pragma unroll
                     for (int i = 0; i < PT; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][0], bv[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int j = J0; j < J1; ++j)
-#pragma unroll
-                    for (int i = 0; i < PT; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][1], bv[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(lav[i][1], lbv[j].y, acc[i][j], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
             store_chunk(buf ^ 1);
             __syncthreads();
         }

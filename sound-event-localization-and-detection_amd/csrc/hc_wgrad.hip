@@ -448,7 +448,8 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, Wgrad
         const long long nz = nt - ((Ktot / 2) + bn - 1) / bn;          // column tiles entirely in the upper K half
         if (nz > 0 && mz > 0) { p->mz = (int)mz; p->nact = (int)(nt - nz); tiles -= mz * nz; }
     }
-    long long slots = (bm == 64 ? 4 : 2) * 256;
+    // resident workgroups per CU (LDS-limited): 128x128 / 192x80 / 96x128 -> 2, 64x80 -> 3, 64x64 -> 4
+    long long slots = (bm == 64 ? (bn == 64 ? 4 : 3) : 2) * 256;
     if (const char* e = getenv("SELD_WGRAD_WGS")) slots = atoll(e) > 0 ? atoll(e) : slots;
     long long want = slots / tiles;                       // floor: stay within one generation
     const long long maxs = (Ptot + 511) / 512;            // at least 512 positions per split
@@ -462,11 +463,12 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, Wgrad
     return ns < 1 ? 1 : ns;
 }
 
-// tile configuration: 0 = 128 x 128 (waves 2 x 2), 1 = 192 x 80 for short K (first layer), 2 = 64 x 64 (small layers)
+// tile configuration: 0 = 128 x 128 (waves 2 x 2), 1 = 192 x 80 for short K (first layer), 2 = 64 x 64 (small layers),
+// 3 = 96 x 128, 4 = 64 x 80 (short K: a third of the float-atomic chain per gradient element of 192 x 80, x re-read 3x)
 static int wgrad_cfg(const seld_conv_desc* d) {
     const int Ktot = d->Cin * d->k[0] * d->k[1];
     if (const char* e = getenv("SELD_WGRAD_CFG")) return atoi(e);     // tuning aid
-    if (Ktot <= 80 && d->Cout > 64) return 1;
+    if (Ktot <= 80 && d->Cout > 64) return (d->Cout % 64 == 0) ? 4 : 1;
     if (d->Cout <= 64 || Ktot <= 64) return 2;
     // few 128 x 128 tiles and a short reduction (positions / 512 splits at most): take 64 x 64 tiles so that
     // the launch still has >= 2 workgroups per CU
@@ -536,12 +538,13 @@ static int wgrad_run(const seld_conv_desc* d, const float* x, const float* dy, f
         if (rc) return rc;
     }
     const int cfg = wgrad_cfg(d);
-    static const int tile_m[4] = {128, 192, 64, 96}, tile_n[4] = {128, 80, 64, 128};
+    static const int tile_m[5] = {128, 192, 64, 96, 64}, tile_n[5] = {128, 80, 64, 128, 80};
     p.nsplit = wgrad_splits(d, o, tile_m[cfg], tile_n[cfg], &p);
     if (hc_wgrad_row_ok(p)) hc_wgrad_row_launch(p, cfg, st);           // row-chunk staging (hc_wgrad_row.hip)
     else if (cfg == 0) launch_wgrad<2, 4, 4>(p, st);
     else if (cfg == 1) launch_wgrad<4, 3, 5>(p, st);
     else if (cfg == 3) launch_wgrad<2, 3, 4>(p, st);
+    else if (cfg == 4) launch_wgrad<4, 1, 5>(p, st);
     else launch_wgrad<2, 2, 2>(p, st);
     rc = check_launch();
     if (rc) return rc;
@@ -556,7 +559,7 @@ int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
     int kh = d->k[0], kw = d->k[1];
     if (!((kh == 1 && kw == 1) || (kh == 1 && kw == 3) || (kh == 3 && kw == 3))) kh = kw = 0;
     const int cfg = wgrad_cfg(d);
-    const char* t = cfg == 0 ? "2, 4, 4" : (cfg == 1 ? "4, 3, 5" : (cfg == 3 ? "2, 3, 4" : "2, 2, 2"));
+    const char* t = cfg == 0 ? "2, 4, 4" : (cfg == 1 ? "4, 3, 5" : (cfg == 3 ? "2, 3, 4" : (cfg == 4 ? "4, 1, 5" : "2, 2, 2")));
     int o[2];
     hc_out_shape(d, o);
     const bool fast = (o[1] % 4 == 0) && o[1] >= 32 && d->stride[1] == 1 && !getenv("SELD_WGRAD_SLOW");

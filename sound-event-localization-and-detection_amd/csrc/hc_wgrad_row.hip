@@ -232,13 +232,14 @@ static void launch_row(const WgradP& p, hipStream_t st) {
     else hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 1>), grid, dim3(256), 0, st, p);
 }
 
-// cfg as in wgrad_cfg(): 0 = 128 x 128, 1 = 192 x 80, 2 = 64 x 64, 3 = 96 x 128
+// cfg as in wgrad_cfg(): 0 = 128 x 128, 1 = 192 x 80, 2 = 64 x 64, 3 = 96 x 128, 4 = 64 x 80
 void hc_wgrad_row_launch(const WgradP& p_in, int cfg, hipStream_t st) {
     WgradP p = p_in;
     p.dbg = getenv("SELD_WGRAD_DBG") ? atoi(getenv("SELD_WGRAD_DBG")) : 0;
     if (cfg == 0) launch_row<2, 4, 4>(p, st);
     else if (cfg == 1) launch_row<4, 3, 5>(p, st);
     else if (cfg == 3) launch_row<2, 3, 4>(p, st);
+    else if (cfg == 4) launch_row<4, 1, 5>(p, st);
     else launch_row<2, 2, 2>(p, st);
 }
 

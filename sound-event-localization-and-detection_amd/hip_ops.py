@@ -15,6 +15,7 @@ class KernelTimer:
 
     def __init__(self):
         self.active = False
+        self.only = None       # None: every conv launch; else the set of kernel labels to time (the others run bare)
         self.records = []      # (label, start_event, end_event, flops, bytes)
 
     def reset(self):
@@ -56,9 +57,18 @@ def _label(desc, which):
     return buf.value.decode()
 
 
+_label_cache = {}
+
+
 class _Timed:
     def __init__(self, desc, which):
         self.on = kernel_timer.active
+        if self.on and kernel_timer.only is not None:
+            key = (bytes(desc), which)
+            lab = _label_cache.get(key)
+            if lab is None:
+                lab = _label_cache[key] = _label(desc, which)
+            self.on = lab in kernel_timer.only
         if self.on:
             self.desc, self.which = desc, which
             self.e0 = torch.cuda.Event(enable_timing=True)

@@ -115,8 +115,9 @@ def test_conv_vec_kernel_vs_oracle(algebra, shape, cout, k, pad, dil, cfg, monke
     monkeypatch.setenv("SELD_CONV_CFG", cfg)
     kk = (k,) if isinstance(k, int) else k
     desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
-    assert H._label(desc, 0).startswith("hc_conv_vec_kernel<" + cfg.replace(",", ", ")), H._label(desc, 0)
-    assert H._label(desc, 1).startswith("hc_conv_vec_kernel<" + cfg.replace(",", ", ")), H._label(desc, 1)
+    want = "hc_conv_vec_kernel<" + cfg.replace(",", ", ")
+    assert H._label(desc, 0).startswith(want), H._label(desc, 0)
+    assert H._label(desc, 1).startswith(want), H._label(desc, 1)
     gen = torch.Generator().manual_seed(4321)
     x = torch.randn(shape, generator=gen)
     wshape = (cout // algebra, shape[1] // algebra) + tuple(kk)
