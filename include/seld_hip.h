@@ -98,6 +98,33 @@ int seld_hc_conv_bwd_weight(const seld_conv_desc* d, const float* x, const float
 int seld_hc_conv_bwd_weight_acc(const seld_conv_desc* d, const float* x, const float* dy,
                                 float* const dw[8], float* dbias /* nullable */, void* stream);
 
+/* ---- two convolutions of one geometry in one launch ------------------------------------------------------
+ * A residual block calls the hypercomplex convolution twice on the same tensor with the same geometry:
+ * conv1_filter | conv1_gate (model.py:121-122) and conv2_skip | conv2_residual (model.py:130-132).  The pair entry
+ * points run both in one launch (forward: the grid carries both; data gradient: ONE kernel sums both contributions,
+ * its reduction runs over dyA then dyB; weight gradient: the grid carries both).  The layers are ~70 us each on an
+ * MI355X, so a launch's fixed cost is a third of it.
+ * seld_hc_conv_pair_supported(d, which) (which: 0 forward, 1 data gradient, 2 weight gradient) tells whether the
+ * pair form runs for this shape; if not, the entry point returns SELD_EUNSUPPORTED and the caller issues the two
+ * single calls. */
+int seld_hc_conv_pair_supported(const seld_conv_desc* d, int32_t which);
+
+int seld_hc_conv_pair_fwd(const seld_conv_desc* d, const float* x, const float* const wA[8], const float* const wB[8],
+                          const float* biasA /* nullable */, const float* biasB /* nullable */, float* yA, float* yB,
+                          int32_t epilogueA, int32_t epilogueB, const float* addendA /* nullable */,
+                          const float* addendB /* nullable */, float* statsA /* nullable */,
+                          float* statsB /* nullable */, void* stream);
+
+/* dx = dgrad(dyA, wA) + dgrad(dyB, wB); workspace: 2 * seld_hc_conv_bwd_data_workspace(d) bytes, required */
+int seld_hc_conv_pair_bwd_data(const seld_conv_desc* d, const float* dyA, const float* dyB, const float* const wA[8],
+                               const float* const wB[8], float* dx, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
+/* dwA[c] += ..., dwB[c] += ..., dbiasA += ..., dbiasB += ... (bias gradients nullable) */
+int seld_hc_conv_pair_bwd_weight_acc(const seld_conv_desc* d, const float* x, const float* dyA, const float* dyB,
+                                     float* const dwA[8], float* const dwB[8], float* dbiasA, float* dbiasB,
+                                     void* stream);
+
 /* Diagnostics: label of the kernel symbol a call would launch ("hc_conv_kernel<4, 4, 1, 3>"), so that
  * HIP-event timings taken by the caller can be matched with rocprofv3's per-kernel statistics.
  * which: 0 forward, 1 data gradient, 2 weight gradient.  buflen >= 48. */

@@ -32,6 +32,18 @@ struct ConvP {
     float* dst;
     const float* addend;
     float* stats;
+    // A second convolution of the SAME geometry in the same launch (hc_conv_vec_kernel only; nslots = 2).
+    //   forward : same src, blockIdx.z selects {w, bias, dst, addend, stats, epilogue} or the *2 set
+    //             (filter | gate and skip | residual of a residual block read the same tensor, model.py:121-132)
+    //   dgrad   : dst = dgrad(src, w) + dgrad(src2, w2): the K loop runs over both sources in turn
+    int nslots;
+    int epilogue2;
+    WPtrs w2;
+    const float* src2;
+    const float* bias2;
+    float* dst2;
+    const float* addend2;
+    float* stats2;
 };
 
 struct WgradP {
@@ -49,6 +61,11 @@ struct WgradP {
     const float* x;
     const float* dy;
     WPtrsMut gw;       // component gradients (accumulated into)
+    // a second weight gradient with the same x in the same launch (hc_wgrad_row_kernel only): blockIdx.y selects
+    // {dy, gw} or {dy2, gw2}
+    int nslots;
+    const float* dy2;
+    WPtrsMut gw2;
     int mz, nact, nt;  // tile enumeration without the zero quadrant: the first mz row tiles have nact column tiles, the rest nt
     int dbg;           // SELD_WGRAD_DBG: timing experiments (wrong results): 1 = no loads in the loop, 2 = no LDS stores
 };

@@ -642,6 +642,79 @@ extern "C" int seld_hc_conv_bwd_data_ex(const seld_conv_desc* d, const float* dy
 
 namespace seld {
 int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen);
+int hc_wgrad_pair_ok(const seld_conv_desc* d);
+}
+
+// ---- two convolutions of one geometry in one launch (filter | gate, skip | residual of a residual block) ---------
+// which: 0 forward, 1 data gradient, 2 weight gradient.  1 if the pair entry point below will run, else 0 (the caller
+// then issues the two single calls).
+extern "C" int seld_hc_conv_pair_supported(const seld_conv_desc* d, int32_t which) {
+    if (hc_validate(d)) return 0;
+    int o[2];
+    hc_out_shape(d, o);
+    if (o[0] <= 0 || o[1] <= 0) return 0;
+    if (which == 2) return hc_wgrad_pair_ok(d);
+    ConvP p{};
+    if (which == 0) fill_fwd(p, d, nullptr, o);
+    else { fill_dgrad(p, d, nullptr, o); p.wt = 1; }
+    p.nslots = 2;
+    if (which == 0) { int dummy; if (hc_conv_smallk_try(p, nullptr, &dummy, 1)) return 0; }
+    const TileCfg c = pick_cfg(p.Cdst, p.Ptot);
+    return hc_conv_vec_chunk(p, which, c.ct, c.pt) ? 1 : 0;
+}
+
+extern "C" int seld_hc_conv_pair_fwd(const seld_conv_desc* d, const float* x, const float* const wA[8],
+                                     const float* const wB[8], const float* biasA, const float* biasB, float* yA,
+                                     float* yB, int32_t epilogueA, int32_t epilogueB, const float* addendA,
+                                     const float* addendB, float* statsA, float* statsB, void* stream) {
+    if (!seld_hc_conv_pair_supported(d, 0)) return SELD_EUNSUPPORTED;
+    if (!x || !wA || !wB || !yA || !yB) return SELD_EINVAL;
+    if (((epilogueA & SELD_EPI_ADD) && !addendA) || ((epilogueB & SELD_EPI_ADD) && !addendB)) return SELD_EINVAL;
+    if (((epilogueA & SELD_EPI_STATS) && !statsA) || ((epilogueB & SELD_EPI_STATS) && !statsB)) return SELD_EINVAL;
+    int o[2];
+    hc_out_shape(d, o);
+    ConvP p{};
+    fill_fwd(p, d, wA, o);
+    p.epilogue = epilogueA; p.src = x; p.bias = biasA; p.dst = yA; p.addend = addendA; p.stats = statsA;
+    p.nslots = 2;
+    for (int i = 0; i < 8; ++i) p.w2.p[i] = (i < d->algebra) ? wB[i] : nullptr;
+    p.epilogue2 = epilogueB; p.src2 = x; p.bias2 = biasB; p.dst2 = yB; p.addend2 = addendB; p.stats2 = statsB;
+    const TileCfg c = pick_cfg(p.Cdst, p.Ptot);
+    if (!hc_conv_vec_try(p, MODE_FWD, c.ct, c.pt, (hipStream_t)stream)) return SELD_EUNSUPPORTED;
+    return check_launch();
+}
+
+// dx = dgrad(dyA, wA) + dgrad(dyB, wB).  workspace: 2 * seld_hc_conv_bwd_data_workspace(d) bytes (required).
+extern "C" int seld_hc_conv_pair_bwd_data(const seld_conv_desc* d, const float* dyA, const float* dyB,
+                                          const float* const wA[8], const float* const wB[8], float* dx,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!seld_hc_conv_pair_supported(d, 1)) return SELD_EUNSUPPORTED;
+    if (!dyA || !dyB || !wA || !wB || !dx) return SELD_EINVAL;
+    const size_t need = seld_hc_conv_bwd_data_workspace(d);
+    if (!workspace || workspace_bytes < 2 * need) return SELD_EINVAL;
+    int o[2];
+    hc_out_shape(d, o);
+    if ((long long)d->Cout * o[0] * o[1] >= (1LL << 28)) return SELD_EUNSUPPORTED;
+    ConvP p{};
+    fill_dgrad(p, d, wA, o);
+    p.src = dyA; p.bias = nullptr; p.dst = dx;
+    p.nslots = 2; p.src2 = dyB;
+    const int per = p.OA * p.IA * p.KH * p.KW;
+    float* wt = (float*)workspace;
+    for (int sl = 0; sl < 2; ++sl) {
+        WPtrs src{};
+        for (int i = 0; i < 8; ++i) src.p[i] = (i < d->algebra) ? (sl ? wB[i] : wA[i]) : nullptr;
+        float* out = wt + (size_t)sl * d->algebra * per;
+        hipLaunchKernelGGL(hc_transpose_w_kernel, dim3((per * d->algebra + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           src, d->algebra, p.OA, p.IA, p.KH * p.KW, out);
+        int rc = check_launch();
+        if (rc) return rc;
+        for (int i = 0; i < d->algebra; ++i) (sl ? p.w2 : p.w).p[i] = out + (size_t)i * per;
+    }
+    p.wt = 1;
+    const TileCfg c = pick_cfg(p.Cdst, p.Ptot);
+    if (!hc_conv_vec_try(p, MODE_DGRAD, c.ct, c.pt, (hipStream_t)stream)) return SELD_EUNSUPPORTED;
+    return check_launch();
 }
 
 // Label of the kernel symbol a call would launch (as rocprofv3 prints the template arguments);

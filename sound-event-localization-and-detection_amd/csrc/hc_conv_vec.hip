@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
 
     __shared__ __attribute__((aligned(16))) float Xs[2][KC][XROW];
     __shared__ __attribute__((aligned(16))) float Ws[2][BC][RS][4];
-    __shared__ unsigned wdelta_s[8];
+    __shared__ unsigned wdelta_s[16];              // [slot][component] byte offsets from p.wmin
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -69,7 +69,19 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     const int A = p.algebra;
     const int CK = (MODE == MODE_FWD ? p.IA : p.OA) * KK;   // K extent of one component block (multiple of KC)
 
-    if (tid < 8) wdelta_s[tid] = p.w.p[tid] ? (unsigned)((const char*)p.w.p[tid] - (const char*)p.wmin) : 0u;
+    if (tid < 16) {
+        const float* wp_ = tid < 8 ? p.w.p[tid] : p.w2.p[tid - 8];
+        wdelta_s[tid] = wp_ ? (unsigned)((const char*)wp_ - (const char*)p.wmin) : 0u;
+    }
+    // Two convolutions in one launch (ConvP::nslots): the K loop runs over slot 0's weights (and, data gradient,
+    // source), then slot 1's.  A data-gradient workgroup sums both into one result; a forward workgroup writes slot
+    // 0's result after the first pass (the stores drain while the second pass computes) and slot 1's at the end.
+    constexpr bool PAIRS = (KH_T == 1);            // only the 1-D layers come in pairs; the 3x3 kernels have no
+                                                   // registers to spare for the second pass
+    const int zslot = 0;
+    const int kslots = (PAIRS && p.nslots > 1) ? 2 : 1;
+    const bool fwd_pair = (MODE == MODE_FWD) && kslots > 1;
+    int wslot = zslot;                             // weight set the next chunk to load belongs to
 
     // ---- buffer descriptor of the streamed operand: based one image before the tile's first image so that the
     // halo of the tile's first row reads (and masks) the end of the previous image instead of wrapping -----------
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     const long long remain = (p.src_elems - imgb * img_elems) * 4;
     const unsigned OOB = 0xFFFFFFF0u;
     const unsigned nrec = remain > (long long)OOB ? OOB : (unsigned)remain;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, nrec, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, nrec, 0x00020000);
 
     const int rem0 = (int)(p0 - img0 * p.dstS);
     auto decode = [&](int local, int* dimg, int* rem) __attribute__((always_inline)) {
@@ -163,6 +175,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wmin, 0, p.wspan, 0x00020000);
     int kq = kbeg / CK;                  // component block the next chunk to load lies in
     int kl = kbeg - kq * CK;             // its offset inside the block (multiple of KC)
+    int lc = 0;                          // chunks of the current slot already requested
     unsigned woff[WI];                   // byte offset from wmin of this item's piece in the chunk to load next
     float wmul[WI];                      // Hamilton sign, or 0 (structural zero / row outside the tensor)
     unsigned wrow[WI];                   // loop-invariant: byte offset of the piece inside a component tensor (a
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
             const int a = v & 7;
             bool zero, neg;
             const int comp = (MODE == MODE_FWD) ? hc_comp(A, a, kq, &zero, &neg) : hc_comp(A, kq, a, &zero, &neg);
-            woff[i] = wdelta_s[comp & 7] + (v & ~15u) + (unsigned)(kl * 4);
+            woff[i] = wdelta_s[wslot * 8 + (comp & 7)] + (v & ~15u) + (unsigned)(kl * 4);
             wmul[i] = ((v & 8u) && !zero) ? (neg ? -1.f : 1.f) : 0.f;
         }
     };
@@ -203,6 +216,18 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     bool comp_switch = true;
     auto load_chunk = [&](auto edgec) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edgec)::value;
+        if (lc == nchunks && wslot + 1 < kslots) {
+            // data gradient of a pair: the first slot's K range is exhausted, go on with the second source / weights
+            wslot = 1;
+            lc = 0;
+            rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src2 + imgb * img_elems), 0, nrec, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < XI; ++j) xoff[j] -= (unsigned)nchunks * xadv;
+            kq = kbeg / CK;
+            kl = kbeg - kq * CK;
+            setup_comp();
+        }
+        ++lc;
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             if (!EDGE) {
@@ -272,10 +297,12 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     // One chunk: [component switch, rare] then ONE basic block -- prefetch of the next chunk into registers, the
     // MFMAs of this one, the registers to the other LDS buffer, barrier.  The prefetch after the last chunk reads
     // through range-checked descriptors and lands in an LDS buffer nobody reads.
+    int gchunk = 0;                    // chunks computed so far (both slots): LDS buffer parity
     auto run_chunks = [&](int cbeg, int cend, auto j0c, auto j1c, auto edgec) __attribute__((always_inline)) {
         constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
         for (int chunk = cbeg; chunk < cend; ++chunk) {
-            const int buf = chunk & 1;
+            const int buf = gchunk & 1;
+            ++gchunk;
             if (comp_switch) setup_comp();
             load_chunk(edgec);
             // The MFMA stream is software-pipelined by hand, one scheduling region per stage (sched_barrier): the
@@ -353,96 +380,131 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     using IC0 = std::integral_constant<int, 0>;
     using ICH = std::integral_constant<int, CT / 2>;
     using ICT = std::integral_constant<int, CT>;
+    // ---- epilogue: lane holds 4 consecutive positions (regs) of channel c0 + j*16 + fr ----------------------
+    auto epilogue = [&](int zs) __attribute__((always_inline)) {
+        float* const dstz = zs ? p.dst2 : p.dst;
+        const float* const addz = zs ? p.addend2 : p.addend;
+        const float* const biasz = zs ? p.bias2 : p.bias;
+        float* const statsz = zs ? p.stats2 : p.stats;
+        const int epi = zs ? p.epilogue2 : p.epilogue;
+        float* const dst0 = dstz + (size_t)img0 * p.Cdst * p.dstS;
+        const float* const add0 = addz ? addz + (size_t)img0 * p.Cdst * p.dstS : nullptr;
+        int poff[PT];
+    #pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            int dimg, rem;
+            decode(wave * (PT * 16) + i * 16 + fk * 4, &dimg, &rem);
+            poff[i] = dimg * p.Cdst * p.dstS + rem;
+        }
+    #pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int ch = chan_of(j * 16 + fr);
+            const bool chok = ch < p.Cdst;
+            const float bvv = (chok && biasz) ? biasz[ch] : 0.0f;
+            float s1 = 0.f, s2 = 0.f;
+    #pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const long long pos = p0 + wave * (PT * 16) + i * 16 + fk * 4;
+                const floatx4 v = acc[i][j];
+                if (chok && pos < p.Ptot && !(p.pairing & 8)) {
+                    const size_t off = (size_t)(poff[i] + ch * p.dstS);
+                    float4 o = make_float4(v[0] + bvv, v[1] + bvv, v[2] + bvv, v[3] + bvv);
+                    if (epi & SELD_EPI_ADD) {
+                        const float4 ad = *reinterpret_cast<const float4*>(add0 + off);
+                        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                    }
+                    if (epi & SELD_EPI_ACCUMULATE) {
+                        const float4 old = *reinterpret_cast<const float4*>(dst0 + off);
+                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                    }
+                    *reinterpret_cast<float4*>(dst0 + off) = o;
+                    s1 += o.x + o.y + o.z + o.w;
+                    s2 += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+                }
+            }
+            if (epi & SELD_EPI_STATS) {
+                s1 += __shfl_xor(s1, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (fk == 0) {
+                    float* redbuf = &Xs[0][0][0];          // the K loop is over: the staging buffers are free
+                    redbuf[(wave * BC + j * 16 + fr) * 2 + 0] = s1;
+                    redbuf[(wave * BC + j * 16 + fr) * 2 + 1] = s2;
+                }
+            }
+        }
+        if (epi & SELD_EPI_STATS) {
+            static_assert(sizeof(Xs) >= 4 * BC * 2 * sizeof(float), "statistics scratch fits the X staging buffers");
+            __syncthreads();
+            const float* redbuf = &Xs[0][0][0];
+            float* rep = statsz + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
+            for (int t = tid; t < BC; t += 256) {
+                const int ch = chan_of(t);
+                if (ch < p.Cdst) {
+                    float a1 = 0.f, a2 = 0.f;
+    #pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) {
+                        a1 += redbuf[(wv * BC + t) * 2 + 0];
+                        a2 += redbuf[(wv * BC + t) * 2 + 1];
+                    }
+                    atomicAdd(rep + ch, a1);
+                    atomicAdd(rep + p.Cdst + ch, a2);
+                }
+            }
+        }
+    };
+
+    // (data gradient of a pair: the chunk ranges are simply run again for the second source; load_chunk's state
+    // machine switches descriptor and weights by itself.  Written as straight-line repeats, not as a loop over the
+    // slots: the nested loop cost the 12-tile kernels 100+ VGPRs.)
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    };
     auto run_all = [&](auto edgec) __attribute__((always_inline)) {
         if (mixed_wg) {
             const int csplit = (half_k - kbeg) / KC;          // first chunk of the upper K half
             if (p.skip_mode == 1) {                           // forward: primal tiles (lower half) see zeros there
                 run_chunks(0, csplit, IC0{}, ICT{}, edgec);
                 run_chunks(csplit, nchunks, ICH{}, ICT{}, edgec);
+                if (fwd_pair) {
+                    epilogue(0);
+                    zero_acc();
+                    run_chunks(0, csplit, IC0{}, ICT{}, edgec);
+                    run_chunks(csplit, nchunks, ICH{}, ICT{}, edgec);
+                }
             } else {                                          // dgrad: dual tiles (upper half) see zeros in the lower K half
                 run_chunks(0, csplit, IC0{}, ICH{}, edgec);
                 run_chunks(csplit, nchunks, IC0{}, ICT{}, edgec);
+                if (kslots > 1) {
+                    run_chunks(0, csplit, IC0{}, ICH{}, edgec);
+                    run_chunks(csplit, nchunks, IC0{}, ICT{}, edgec);
+                }
             }
-        } else {
+        } else if (fwd_pair) {
             run_chunks(0, nchunks, IC0{}, ICT{}, edgec);
+            epilogue(0);
+            zero_acc();
+            run_chunks(0, nchunks, IC0{}, ICT{}, edgec);
+        } else {
+            run_chunks(0, kslots * nchunks, IC0{}, ICT{}, edgec);
         }
     };
     if (edge_wg) run_all(ETrue{});
     else run_all(EFalse{});
+    epilogue(fwd_pair ? 1 : 0);
 
-    // ---- epilogue: lane holds 4 consecutive positions (regs) of channel c0 + j*16 + fr ----------------------
-    float* const dst0 = p.dst + (size_t)img0 * p.Cdst * p.dstS;
-    const float* const add0 = p.addend ? p.addend + (size_t)img0 * p.Cdst * p.dstS : nullptr;
-    int poff[PT];
-#pragma unroll
-    for (int i = 0; i < PT; ++i) {
-        int dimg, rem;
-        decode(wave * (PT * 16) + i * 16 + fk * 4, &dimg, &rem);
-        poff[i] = dimg * p.Cdst * p.dstS + rem;
-    }
-#pragma unroll
-    for (int j = 0; j < CT; ++j) {
-        const int ch = chan_of(j * 16 + fr);
-        const bool chok = ch < p.Cdst;
-        const float bvv = (chok && p.bias) ? p.bias[ch] : 0.0f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const long long pos = p0 + wave * (PT * 16) + i * 16 + fk * 4;
-            const floatx4 v = acc[i][j];
-            if (chok && pos < p.Ptot && !(p.pairing & 8)) {
-                const size_t off = (size_t)(poff[i] + ch * p.dstS);
-                float4 o = make_float4(v[0] + bvv, v[1] + bvv, v[2] + bvv, v[3] + bvv);
-                if (p.epilogue & SELD_EPI_ADD) {
-                    const float4 ad = *reinterpret_cast<const float4*>(add0 + off);
-                    o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
-                }
-                if (p.epilogue & SELD_EPI_ACCUMULATE) {
-                    const float4 old = *reinterpret_cast<const float4*>(dst0 + off);
-                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-                }
-                *reinterpret_cast<float4*>(dst0 + off) = o;
-                s1 += o.x + o.y + o.z + o.w;
-                s2 += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
-            }
-        }
-        if (p.epilogue & SELD_EPI_STATS) {
-            s1 += __shfl_xor(s1, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (fk == 0) {
-                float* redbuf = &Xs[0][0][0];          // the K loop is over: the staging buffers are free
-                redbuf[(wave * BC + j * 16 + fr) * 2 + 0] = s1;
-                redbuf[(wave * BC + j * 16 + fr) * 2 + 1] = s2;
-            }
-        }
-    }
-    if (p.epilogue & SELD_EPI_STATS) {
-        static_assert(sizeof(Xs) >= 4 * BC * 2 * sizeof(float), "statistics scratch fits the X staging buffers");
-        __syncthreads();
-        const float* redbuf = &Xs[0][0][0];
-        float* rep = p.stats + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
-        for (int t = tid; t < BC; t += 256) {
-            const int ch = chan_of(t);
-            if (ch < p.Cdst) {
-                float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < 4; ++wv) {
-                    a1 += redbuf[(wv * BC + t) * 2 + 0];
-                    a2 += redbuf[(wv * BC + t) * 2 + 1];
-                }
-                atomicAdd(rep + ch, a1);
-                atomicAdd(rep + p.Cdst + ch, a2);
-            }
-        }
-    }
 }
 
 // Can this problem run on the vector-staging kernel with tile (ct, pt)?  Returns the K chunk (36 / 24) or 0.
 int hc_conv_vec_chunk(const ConvP& p, int mode, int ct, int pt) {
     if (getenv("SELD_CONV_NOVEC")) return 0;
     if (!(ct == 12 || ct == 6) || pt != 1) return 0;
+    if (p.nslots > 1 && p.KH != 1) return 0;                   // pairs: 1-D layers only
+    if (p.nslots > 1 && ((p.epilogue | p.epilogue2) & SELD_EPI_STATS)) return 0;   // statistics scratch is the staged chunk
     if (!(mode == MODE_FWD || p.wt)) return 0;
     if (p.SDh != 1 || p.SDw != 1 || p.SMh != 1 || p.SMw != 1) return 0;
     if (p.dstW % 4 != 0) return 0;
@@ -471,11 +533,13 @@ int hc_conv_vec_try(const ConvP& p_in, int mode, int ct, int pt, hipStream_t st)
     // the component tensors are addressed as wmin + 32-bit byte offset: they must lie within 4 GB of each other
     const size_t comp_bytes = (size_t)p.OA * p.IA * p.KH * p.KW * sizeof(float);
     uintptr_t lo = UINTPTR_MAX, hi = 0;
-    for (int i = 0; i < p.algebra; ++i) {
-        const uintptr_t a = (uintptr_t)p.w.p[i];
-        lo = a < lo ? a : lo;
-        hi = a > hi ? a : hi;
-    }
+    if (p.nslots < 1) p.nslots = 1;
+    for (int sl = 0; sl < p.nslots; ++sl)
+        for (int i = 0; i < p.algebra; ++i) {
+            const uintptr_t a = (uintptr_t)(sl ? p.w2.p[i] : p.w.p[i]);
+            lo = a < lo ? a : lo;
+            hi = a > hi ? a : hi;
+        }
     if (hi - lo + comp_bytes >= 0xFFFFFFF0ull) return 0;
     p.wmin = (const float*)lo;
     p.wspan = (unsigned)(hi - lo + comp_bytes);

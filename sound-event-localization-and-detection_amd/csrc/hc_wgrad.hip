@@ -451,6 +451,7 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, Wgrad
     // resident workgroups per CU (LDS-limited): 128x128 / 192x80 / 96x128 -> 2, 64x80 -> 3, 64x64 -> 4
     long long slots = (bm == 64 ? (bn == 64 ? 4 : 3) : 2) * 256;
     if (const char* e = getenv("SELD_WGRAD_WGS")) slots = atoll(e) > 0 ? atoll(e) : slots;
+    tiles *= (p->nslots > 1 ? 2 : 1);                     // a pair launch carries two gradients
     long long want = slots / tiles;                       // floor: stay within one generation
     const long long maxs = (Ptot + 511) / 512;            // at least 512 positions per split
     if (want > maxs) want = maxs;
@@ -508,13 +509,15 @@ static void launch_wgrad(const WgradP& p, hipStream_t st) {
 #undef SELD_WG
 }
 
-static int wgrad_run(const seld_conv_desc* d, const float* x, const float* dy, float* const dw[8], float* dbias,
-                     int accumulate, hipStream_t st) {
+// One weight gradient, or (dy2 != nullptr) the two of a pair that shares x and the geometry.
+static int wgrad_run2(const seld_conv_desc* d, const float* x, const float* dy, float* const dw[8], float* dbias,
+                      const float* dy2, float* const dw2[8], float* dbias2, int accumulate, hipStream_t st) {
     int rc = hc_validate(d);
     if (rc) return rc;
     int o[2];
     hc_out_shape(d, o);
     if (o[0] <= 0 || o[1] <= 0 || !x || !dy || !dw) return SELD_EINVAL;
+    if (dy2 && !dw2) return SELD_EINVAL;
     WgradP p{};
     p.algebra = d->algebra; p.N = d->N; p.Cin = d->Cin; p.Cout = d->Cout;
     p.inH = d->in[0]; p.inW = d->in[1]; p.outH = o[0]; p.outW = o[1];
@@ -525,22 +528,32 @@ static int wgrad_run(const seld_conv_desc* d, const float* x, const float* dy, f
     p.inS = p.inH * p.inW; p.outS = p.outH * p.outW;
     p.Ptot = (long long)d->N * p.outS;
     p.x = x; p.dy = dy;
-    for (int i = 0; i < 8; ++i) p.gw.p[i] = (i < d->algebra) ? dw[i] : nullptr;
+    p.nslots = dy2 ? 2 : 1;
+    p.dy2 = dy2;
+    for (int i = 0; i < 8; ++i) {
+        p.gw.p[i] = (i < d->algebra) ? dw[i] : nullptr;
+        p.gw2.p[i] = (dy2 && i < d->algebra) ? dw2[i] : nullptr;
+    }
     if (!accumulate) {
-        ZeroP z{};
-        const long long per = (long long)p.OA * p.IA * p.KH * p.KW;
-        int n = 0;
-        for (int i = 0; i < d->algebra; ++i) { z.p[n] = dw[i]; z.n[n] = per; ++n; }
-        if (dbias) { z.p[n] = dbias; z.n[n] = d->Cout; ++n; }
-        const long long blocks = (per + 255) / 256;
-        hipLaunchKernelGGL(zero_many_kernel, dim3((unsigned)(blocks > 64 ? 64 : blocks), n), dim3(256), 0, st, z);
-        rc = check_launch();
-        if (rc) return rc;
+        for (int sl = 0; sl < p.nslots; ++sl) {
+            ZeroP z{};
+            const long long per = (long long)p.OA * p.IA * p.KH * p.KW;
+            float* const* dws = sl ? dw2 : dw;
+            float* db = sl ? dbias2 : dbias;
+            int n = 0;
+            for (int i = 0; i < d->algebra; ++i) { z.p[n] = dws[i]; z.n[n] = per; ++n; }
+            if (db) { z.p[n] = db; z.n[n] = d->Cout; ++n; }
+            const long long blocks = (per + 255) / 256;
+            hipLaunchKernelGGL(zero_many_kernel, dim3((unsigned)(blocks > 64 ? 64 : blocks), n), dim3(256), 0, st, z);
+            rc = check_launch();
+            if (rc) return rc;
+        }
     }
     const int cfg = wgrad_cfg(d);
     static const int tile_m[5] = {128, 192, 64, 96, 64}, tile_n[5] = {128, 80, 64, 128, 80};
     p.nsplit = wgrad_splits(d, o, tile_m[cfg], tile_n[cfg], &p);
     if (hc_wgrad_row_ok(p)) hc_wgrad_row_launch(p, cfg, st);           // row-chunk staging (hc_wgrad_row.hip)
+    else if (dy2) return SELD_EUNSUPPORTED;                            // pairs only on the row kernel
     else if (cfg == 0) launch_wgrad<2, 4, 4>(p, st);
     else if (cfg == 1) launch_wgrad<4, 3, 5>(p, st);
     else if (cfg == 3) launch_wgrad<2, 3, 4>(p, st);
@@ -548,11 +561,30 @@ static int wgrad_run(const seld_conv_desc* d, const float* x, const float* dy, f
     else launch_wgrad<2, 2, 2>(p, st);
     rc = check_launch();
     if (rc) return rc;
-    if (dbias) {
-        hipLaunchKernelGGL(channel_sum_kernel, dim3(d->Cout), dim3(256), 0, st, dy, d->N, d->Cout, p.outS, dbias);
-        rc = check_launch();
+    for (int sl = 0; sl < p.nslots; ++sl) {
+        float* db = sl ? dbias2 : dbias;
+        if (db) {
+            hipLaunchKernelGGL(channel_sum_kernel, dim3(d->Cout), dim3(256), 0, st, sl ? dy2 : dy, d->N, d->Cout, p.outS, db);
+            rc = check_launch();
+            if (rc) return rc;
+        }
     }
     return rc;
+}
+
+static int wgrad_run(const seld_conv_desc* d, const float* x, const float* dy, float* const dw[8], float* dbias,
+                     int accumulate, hipStream_t st) {
+    return wgrad_run2(d, x, dy, dw, dbias, nullptr, nullptr, nullptr, accumulate, st);
+}
+
+// Would a pair launch run (row kernel eligibility)?
+int hc_wgrad_pair_ok(const seld_conv_desc* d) {
+    int o[2];
+    hc_out_shape(d, o);
+    WgradP p{};
+    p.KH = d->k[0]; p.KW = d->k[1]; p.sw = d->stride[1]; p.outW = o[1]; p.split_len = 32;
+    p.Cout = d->Cout; p.Cin = d->Cin; p.outS = o[0] * o[1]; p.inS = d->in[0] * d->in[1];
+    return hc_wgrad_row_ok(p) ? 1 : 0;
 }
 
 int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
@@ -573,6 +605,15 @@ int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
 
 }  // namespace seld
 using namespace seld;
+
+// dwA[c] += wgrad(x, dyA), dwB[c] += wgrad(x, dyB) (+ bias gradients): one launch for two convolutions that read
+// the same input with the same geometry.  SELD_EUNSUPPORTED when the shape does not qualify: call the single form twice.
+extern "C" int seld_hc_conv_pair_bwd_weight_acc(const seld_conv_desc* d, const float* x, const float* dyA,
+                                                const float* dyB, float* const dwA[8], float* const dwB[8],
+                                                float* dbiasA, float* dbiasB, void* stream) {
+    if (!dyB || !dwB) return SELD_EINVAL;
+    return wgrad_run2(d, x, dyA, dwA, dbiasA, dyB, dwB, dbiasB, 1, (hipStream_t)stream);
+}
 
 extern "C" size_t seld_hc_conv_bwd_weight_workspace(const seld_conv_desc* d) {
     (void)d;

@@ -48,6 +48,8 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int CK = p.IA * KK;
+    const float* const dyz = blockIdx.y ? p.dy2 : p.dy;            // pair launch: which of the two gradients
+    const WPtrsMut& gwz = blockIdx.y ? p.gw2 : p.gw;
 
     if (p.algebra == 8 && m0 + BM <= (p.Cout >> 1) && n0 >= (p.Ktot >> 1)) return;   // zero quadrant
 
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
     // `advance` is false for the prefetch issued during the last step: it re-reads that step (valid addresses) into
     // the LDS buffer nobody reads, so the loop body needs no branch around its loads and stores.
     auto load_chunk = [&](bool advance) __attribute__((always_inline)) {
-        const float* abase = p.dy + (long long)t_img * dy_img + (long long)t_oh * p.outW + t_ow;
+        const float* abase = dyz + (long long)t_img * dy_img + (long long)t_oh * p.outW + t_ow;
         const float* bbase = p.x + (long long)t_img * x_img + (long long)(t_oh * p.sh - p.ph) * p.inW + (t_ow - p.pw);
         const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, nrec_a, 0x00020000);
         const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bbase, 0, nrec_b, 0x00020000);
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
                 const int comp = hc_comp(p.algebra, pp, qq, &zero, &neg);
                 if (zero) continue;
                 const float v = acc[i][j][r];
-                atomicAdd(p.gw.p[comp] + (size_t)o * CK + ckl, neg ? -v : v);
+                atomicAdd(gwz.p[comp] + (size_t)o * CK + ckl, neg ? -v : v);
             }
         }
     }
@@ -226,7 +228,7 @@ bool hc_wgrad_row_ok(const WgradP& p) {
 template <int WRW, int RT, int CTL>
 static void launch_row(const WgradP& p, hipStream_t st) {
     constexpr int BM = WRW * RT * 16, BN = (4 / WRW) * CTL * 16;
-    dim3 grid(p.mz * p.nact + ((p.Cout + BM - 1) / BM - p.mz) * p.nt, 1, p.nsplit);
+    dim3 grid(p.mz * p.nact + ((p.Cout + BM - 1) / BM - p.mz) * p.nt, p.nslots > 1 ? 2 : 1, p.nsplit);
     if (p.KH == 3) hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 3, 3>), grid, dim3(256), 0, st, p);
     else if (p.KW == 3) hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 3>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 1>), grid, dim3(256), 0, st, p);

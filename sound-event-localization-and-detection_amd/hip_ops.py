@@ -61,7 +61,8 @@ _label_cache = {}
 
 
 class _Timed:
-    def __init__(self, desc, which):
+    def __init__(self, desc, which, mult=1):
+        self.mult = mult
         self.on = kernel_timer.active
         if self.on and kernel_timer.only is not None:
             key = (bytes(desc), which)
@@ -83,7 +84,7 @@ class _Timed:
         if self.on:
             self.e1.record()
             fl, by = conv_work(self.desc, self.which)
-            kernel_timer.records.append((_label(self.desc, self.which), self.e0, self.e1, fl, by))
+            kernel_timer.records.append((_label(self.desc, self.which), self.e0, self.e1, fl * self.mult, by * self.mult))
         return False
 
 
@@ -262,6 +263,117 @@ class HyperConvAddFn(torch.autograd.Function):
 
 def hyper_conv_add(x, ws, bias, addend, stride, padding, dilation):
     return HyperConvAddFn.apply(x, bias, addend, stride, padding, dilation, *ws)
+
+
+# ======================================================================================
+# two convolutions of one geometry on the same input in one launch
+# ======================================================================================
+_pair_ok_cache = {}
+
+
+def _pair_ok(desc, which):
+    key = (bytes(desc), which)
+    v = _pair_ok_cache.get(key)
+    if v is None:
+        v = _pair_ok_cache[key] = bool(L.lib().seld_hc_conv_pair_supported(ctypes.byref(desc), which))
+    return v
+
+
+class HyperConvPairFn(torch.autograd.Function):
+    """(yA, yB) = (WA (x) x [+ addA], WB (x) x [+ addB]): conv1_filter | conv1_gate (model.py:121-122) and
+    conv2_skip | conv2_residual (model.py:130-132, 210-212) of a residual block, one launch each way
+    (seld_hc_conv_pair_*).  Falls back to the single entry points per direction when a shape does not qualify."""
+
+    @staticmethod
+    def forward(ctx, x, biasA, biasB, addA, addB, stride, padding, dilation, algebra, *ws):
+        wsA, wsB = ws[:algebra], ws[algebra:]
+        k = tuple(wsA[0].shape[2:])
+        desc = make_conv_desc(tuple(x.shape), wsA[0].shape[0] * algebra, algebra, k, stride, padding, dilation)
+        x = _req(x, "x")
+        o = conv_out_shape(desc)
+        yA = torch.empty(_y_shape(desc, o), device=x.device, dtype=torch.float32)
+        yB = torch.empty_like(yA)
+        epiA = L.SELD_EPI_ADD if addA is not None else 0
+        epiB = L.SELD_EPI_ADD if addB is not None else 0
+        with _Timed(desc, 0, 2):
+            rc = L.lib().seld_hc_conv_pair_fwd(
+                ctypes.byref(desc), L.ptr(x), L.ptr_array8([_req(w, "w") for w in wsA]),
+                L.ptr_array8([_req(w, "w") for w in wsB]), L.ptr(_req(biasA, "bias")), L.ptr(_req(biasB, "bias")),
+                L.ptr(yA), L.ptr(yB), ctypes.c_int32(epiA), ctypes.c_int32(epiB), L.ptr(_req(addA, "addend")),
+                L.ptr(_req(addB, "addend")), None, None, L.current_stream())
+        if rc == -4:       # SELD_EUNSUPPORTED: e.g. the two weight sets lie more than 4 GB apart
+            conv_fwd(desc, x, wsA, biasA, out=yA, epilogue=epiA, addend=addA)
+            conv_fwd(desc, x, wsB, biasB, out=yB, epilogue=epiB, addend=addB)
+        else:
+            L.check(rc, "seld_hc_conv_pair_fwd")
+        ctx.desc, ctx.algebra = desc, algebra
+        ctx.params = (wsA, wsB, biasA, biasB)
+        ctx.save_for_backward(x)
+        return yA, yB
+
+    @staticmethod
+    def backward(ctx, dyA, dyB):
+        (x,) = ctx.saved_tensors
+        desc, A = ctx.desc, ctx.algebra
+        wsA, wsB, biasA, biasB = ctx.params
+        dyA, dyB = _req(dyA, "dy"), _req(dyB, "dy")
+        lib = L.lib()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if _pair_ok(desc, 1):
+                dx = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+                lib.seld_hc_conv_bwd_data_workspace.restype = ctypes.c_size_t
+                nbytes = 2 * lib.seld_hc_conv_bwd_data_workspace(ctypes.byref(desc))
+                wsb = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+                with _Timed(desc, 1, 2):
+                    L.check(lib.seld_hc_conv_pair_bwd_data(ctypes.byref(desc), L.ptr(dyA), L.ptr(dyB),
+                                                           L.ptr_array8(list(wsA)), L.ptr_array8(list(wsB)), L.ptr(dx),
+                                                           L.ptr(wsb), ctypes.c_size_t(nbytes), L.current_stream()),
+                            "seld_hc_conv_pair_bwd_data")
+            else:
+                dx = conv_bwd_data(desc, dyA, wsA, tuple(x.shape))
+                dx += conv_bwd_data(desc, dyB, wsB, tuple(x.shape))
+        need_w = any(ctx.needs_input_grad[9:]) or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dwsA, dwsB, dbA, dbB = [None] * A, [None] * A, None, None
+        if need_w:
+            dirA, dirB = _direct_targets(wsA, biasA), _direct_targets(wsB, biasB)
+            if dirA is not None and dirB is not None and _pair_ok(desc, 2):
+                with _Timed(desc, 2, 2):
+                    L.check(lib.seld_hc_conv_pair_bwd_weight_acc(ctypes.byref(desc), L.ptr(x), L.ptr(dyA), L.ptr(dyB),
+                                                                 L.ptr_array8(dirA[0]), L.ptr_array8(dirB[0]),
+                                                                 L.ptr(dirA[1]), L.ptr(dirB[1]), L.current_stream()),
+                            "seld_hc_conv_pair_bwd_weight_acc")
+            else:
+                for ws_, b_, dy_, tgt in ((wsA, biasA, dyA, "A"), (wsB, biasB, dyB, "B")):
+                    d_ = _direct_targets(ws_, b_)
+                    if d_ is not None:
+                        conv_bwd_weight(desc, x, dy_, tuple(ws_[0].shape), b_ is not None, into=d_[0], bias_into=d_[1])
+                    else:
+                        g, gb = conv_bwd_weight(desc, x, dy_, tuple(ws_[0].shape), b_ is not None)
+                        if tgt == "A":
+                            dwsA, dbA = g, gb
+                        else:
+                            dwsB, dbB = g, gb
+        return (dx, dbA, dbB, dyA if ctx.needs_input_grad[3] else None, dyB if ctx.needs_input_grad[4] else None,
+                None, None, None, None, *dwsA, *dwsB)
+
+
+def hyper_conv_pair(x, wsA, biasA, wsB, biasB, stride, padding, dilation, addA=None, addB=None):
+    """Two convolutions of the same input.  One launch when both have the same shape and the kernels support the
+    pair form for it; otherwise exactly the two single calls."""
+    same = (len(wsA) == len(wsB) and tuple(wsA[0].shape) == tuple(wsB[0].shape) and
+            (biasA is None) == (biasB is None) and x.is_cuda)
+    if same:
+        k = tuple(wsA[0].shape[2:])
+        desc = make_conv_desc(tuple(x.shape), wsA[0].shape[0] * len(wsA), len(wsA), k, stride, padding, dilation)
+        if _pair_ok(desc, 0):
+            return HyperConvPairFn.apply(x, biasA, biasB, addA, addB, stride, padding, dilation, len(wsA), *wsA, *wsB)
+
+    def one(ws, bias, add):
+        if add is None:
+            return hyper_conv(x, ws, bias, stride, padding, dilation)
+        return hyper_conv_add(x, ws, bias, add, stride, padding, dilation)
+    return one(wsA, biasA, addA), one(wsB, biasB, addB)
 
 
 # ======================================================================================

@@ -122,13 +122,21 @@ class ResBlock(nn.Module):
             return H.hyper_conv(x, _components(conv), conv.bias, s, p, d)
         return H.hyper_conv_add(x, _components(conv), conv.bias, addend, s, p, d)
 
+    def _conv_pair(self, conv_a, conv_b, x, add_a=None, add_b=None):
+        """Two convolutions of the same input: one launch when they share the geometry (hip_ops.hyper_conv_pair)."""
+        ga, gb = _geom(conv_a), _geom(conv_b)
+        if ga != gb:
+            return self._conv(conv_a, x, add_a), self._conv(conv_b, x, add_b)
+        s, p, d = ga
+        return H.hyper_conv_pair(x, _components(conv_a), conv_a.bias, _components(conv_b), conv_b.bias, s, p, d,
+                                 add_a, add_b)
+
     def fused(self, x, skip_sum=None, need_residual=True):
         """Returns (x_hat + conv2_residual(y)  or None, skip_sum + conv2_skip(y))."""
         bn = self.batch_norm in _TCN_BN
         if bn:
             x = H.bn_act(x, self.batch_filter1, L.SELD_ACT_TANH)
-        yf = self._conv(self.conv1_filter, x)
-        yg = self._conv(self.conv1_gate, x)
+        yf, yg = self._conv_pair(self.conv1_filter, self.conv1_gate, x)
         mask = None
         if self.training and not self.spatial_dropout_rate == 0:
             mask = H.channel_dropout_mask(yf.shape[0], yf.shape[1], self.spatial_dropout_rate, yf.device)
@@ -136,8 +144,10 @@ class ResBlock(nn.Module):
             y = H.gate(yf, yg, self.batch_filter2, self.batch_gate2, mask)
         else:
             y = H.gate_plain(yf, yg, mask)
-        skip = self._conv(self.conv2_skip, y, skip_sum)
-        res = self._conv(self.conv2_residual, y, x) if need_residual else None
+        if need_residual:
+            skip, res = self._conv_pair(self.conv2_skip, self.conv2_residual, y, skip_sum, x)
+        else:
+            skip, res = self._conv(self.conv2_skip, y, skip_sum), None
         return res, skip
 
     def forward(self, x):

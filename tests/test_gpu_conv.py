@@ -151,6 +151,76 @@ def test_conv_vec_kernel_vs_oracle(algebra, shape, cout, k, pad, dil, cfg, monke
     assert torch.allclose(stats[cout:], (ref2 * ref2).sum(dim=red), rtol=1e-4, atol=2e-3)
 
 
+PAIR_CASES = [
+    # algebra, x shape, cout, k, pad, dil, addends
+    (8, (4, 192, 128), 384, 3, 5, 5, False),        # conv1_filter | conv1_gate
+    (8, (3, 384, 64), 192, 1, 0, 1, True),          # conv2_skip (+ running sum) | conv2_residual (+ x)
+    (4, (2, 96, 96), 64, 3, 2, 2, True),
+    (8, (2, 192, 8, 32), 192, (3, 3), 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("algebra,shape,cout,k,pad,dil,adds", PAIR_CASES)
+def test_conv_pair_matches_two_single_calls(algebra, shape, cout, k, pad, dil, adds):
+    """seld_hc_conv_pair_* (one launch for two convolutions of the same input) against the single entry points
+    and, through them, the oracle: outputs, the summed data gradient and both sets of weight gradients."""
+    import ctypes
+    import seld_amd
+    H, L = seld_amd.hip_ops, seld_amd._lib
+    kk = (k,) if isinstance(k, int) else k
+    desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
+    if len(shape) == 3:        # 1-D layers take the pair kernels; 2-D ones fall back to the single calls (fwd, dgrad)
+        assert all(H._pair_ok(desc, w) for w in (0, 1, 2))
+    else:
+        assert not H._pair_ok(desc, 0) and not H._pair_ok(desc, 1) and H._pair_ok(desc, 2)
+    gen = torch.Generator().manual_seed(99)
+    dev = torch.device("cuda:0")
+    wshape = (cout // algebra, shape[1] // algebra) + tuple(kk)
+    x = torch.randn(shape, generator=gen).to(dev)
+    sets = []
+    for _ in range(2):
+        ws = [(torch.randn(wshape, generator=gen) * 0.2).to(dev) for _ in range(algebra)]
+        sets.append((ws, torch.randn(cout, generator=gen).to(dev)))
+    y_shape = H.conv_fwd(desc, x, sets[0][0]).shape
+    addends = [torch.randn(y_shape, generator=gen).to(dev) if adds else None for _ in range(2)]
+    cots = [torch.randn(y_shape, generator=gen).to(dev) for _ in range(2)]
+
+    def run(pair):
+        xs = x.clone().requires_grad_(True)
+        wl = [[w.clone().requires_grad_(True) for w in ws] for ws, _ in sets]
+        bl = [b.clone().requires_grad_(True) for _, b in sets]
+        al = [a.clone().requires_grad_(True) if a is not None else None for a in addends]
+        if pair:
+            ya, yb = H.hyper_conv_pair(xs, wl[0], bl[0], wl[1], bl[1], 1, pad, dil, al[0], al[1])
+        else:
+            one = lambda i: (H.hyper_conv(xs, wl[i], bl[i], 1, pad, dil) if al[i] is None
+                             else H.hyper_conv_add(xs, wl[i], bl[i], al[i], 1, pad, dil))
+            ya, yb = one(0), one(1)
+        ((ya * cots[0]).sum() + (yb * cots[1]).sum()).backward()
+        return (ya, yb, xs.grad, [w.grad for w in wl[0]], [w.grad for w in wl[1]], bl[0].grad, bl[1].grad,
+                [a.grad if a is not None else None for a in al])
+
+    got, ref = run(True), run(False)
+    _close(got[0], ref[0]); _close(got[1], ref[1]); _close(got[2], ref[2])
+    for a, b in zip(got[3] + got[4], ref[3] + ref[4]):
+        _close(a, b)
+    _close(got[5], ref[5]); _close(got[6], ref[6])
+    for a, b in zip(got[7], ref[7]):
+        if b is not None:
+            _close(a, b)
+    # the pair weight-gradient entry point itself (the autograd path above only takes it with FlatAdam's slots)
+    dwa = [torch.zeros(wshape, device=dev) for _ in range(algebra)]
+    dwb = [torch.zeros(wshape, device=dev) for _ in range(algebra)]
+    dba, dbb = torch.zeros(cout, device=dev), torch.zeros(cout, device=dev)
+    L.check(L.lib().seld_hc_conv_pair_bwd_weight_acc(ctypes.byref(desc), L.ptr(x), L.ptr(cots[0]), L.ptr(cots[1]),
+                                                     L.ptr_array8(dwa), L.ptr_array8(dwb), L.ptr(dba), L.ptr(dbb),
+                                                     L.current_stream()), "pair wgrad")
+    torch.cuda.synchronize()
+    for a, b in zip(dwa + dwb, ref[3] + ref[4]):
+        _close(a, b)
+    _close(dba, ref[5]); _close(dbb, ref[6])
+
+
 def test_conv_epilogues():
     import seld_amd
     H = seld_amd.hip_ops
