@@ -46,6 +46,21 @@ def model_kwargs(w, freq=128, time_dim=512):
                 dropout_perc=0.3, class_overlaps=3, use_bias_conv=0, use_bias_linear=1, batch_norm="BN")
 
 
+def pmc_traffic(kernel_label):
+    """HBM-side bytes per launch of `kernel_label` from the committed counter passes of this same command
+    (profiles/*pmc_traffic.json, written by tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
+    runs, FETCH_SIZE doubled as the gfx950 guide prescribes), or None if the kernel was not sampled."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel_label)
+    except (OSError, ValueError, KeyError):
+        return None
+    return round(k["traffic_bytes"]) if k else None
+
+
 def cpu_baseline(w, seconds_budget=25.0):
     """The oracle (CPU restatement of the reference's algorithm, `assembled` = one real conv per layer exactly as
     quaternion_ops.py:125-147 does) timed on this host: same step definition, dropout on, bounded sample."""
@@ -183,7 +198,7 @@ def main():
                 roof = dict(bound="mfma", achieved=dom["tflops"], peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                             frac=round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4))
             roof.update(kernel=dom["kernel"], avg_launch_us=dom["avg_us"], launches_per_step=dom["calls_per_step"],
-                        traffic=None)
+                        traffic=pmc_traffic(dom["kernel"]))
             out["roofline"] = roof
             # the other conv kernels: measured during the warm-up steps (every launch bracketed there)
             per = [rates(k, v, max(args.warmup, 1)) for k, v in survey.items()] if survey else [dom]

@@ -70,10 +70,12 @@ struct WgradP {
     int dbg;           // SELD_WGRAD_DBG: timing experiments (wrong results): 1 = no loads in the loop, 2 = no LDS stores
 };
 
-// blockIdx.x -> (row tile, column tile), skipping the tiles that lie wholly in the dual-quaternion zero quadrant, so
-// that consecutive workgroup ids (which the dispatcher deals round-robin to the 8 XCDs) all carry work.
+// blockIdx.z -> (row tile, column tile), skipping the tiles that lie wholly in the dual-quaternion zero quadrant.
+// The position split is blockIdx.x, the FAST dispatch index: workgroup ids go round-robin to the 8 XCDs, so with a
+// split count that is a multiple of 8 all tiles of one split -- which read the same dy rows / x columns -- run on
+// the same XCD and share its L2 (PMC: the 3x3 layer fetched 3.4x its operands with the tile index fastest).
 __device__ __forceinline__ void wgrad_tile(const WgradP& p, int* mt, int* nt) {
-    const int t = blockIdx.x, head = p.mz * p.nact;
+    const int t = blockIdx.z, head = p.mz * p.nact;
     if (t < head) { *mt = t / p.nact; *nt = t - *mt * p.nact; }
     else { const int u = t - head; const int m = u / p.nt; *mt = p.mz + m; *nt = u - m * p.nt; }
 }

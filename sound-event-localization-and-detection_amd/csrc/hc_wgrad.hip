@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void hc_wgrad_kernel(const WgradP p) {
     wgrad_tile(p, &tile_m, &tile_n);
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    const int split = blockIdx.z;
+    const int split = blockIdx.x;
     const int KH = KH_T ? KH_T : p.KH;
     const int KW = KW_T ? KW_T : p.KW;
     const int KK = KH * KW;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void hc_wgrad32_kernel(const WgradP p) {
     wgrad_tile(p, &tile_m, &tile_n);
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    const int split = blockIdx.z;
+    const int split = blockIdx.x;
     const int KH = KH_T ? KH_T : p.KH;
     const int KW = KW_T ? KW_T : p.KW;
     const int KK = KH * KW;
@@ -457,6 +457,7 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, Wgrad
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     if (want > 1024) want = 1024;
+    if (want >= 16) want -= want % 8;                     // multiple of 8: the tiles of one split share an XCD (wgrad_tile)
     long long len = (Ptot + want - 1) / want;
     len = (len + 31) / 32 * 32;
     const int ns = (int)((Ptot + len - 1) / len);
@@ -495,7 +496,7 @@ static bool wgrad_fast_ok(const WgradP& p) {
 template <int WRW, int RT, int CTL>
 static void launch_wgrad(const WgradP& p, hipStream_t st) {
     constexpr int BM = WRW * RT * 16, BN = (4 / WRW) * CTL * 16;
-    dim3 grid(p.mz * p.nact + ((p.Cout + BM - 1) / BM - p.mz) * p.nt, 1, p.nsplit);
+    dim3 grid(p.nsplit, 1, p.mz * p.nact + ((p.Cout + BM - 1) / BM - p.mz) * p.nt);
     const bool fast = wgrad_fast_ok(p);
 #define SELD_WG(KH_, KW_)                                                                                         \
     do {                                                                                                          \

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
 
     if (p.algebra == 8 && m0 + BM <= (p.Cout >> 1) && n0 >= (p.Ktot >> 1)) return;   // zero quadrant
 
-    const long long pbeg = (long long)blockIdx.z * p.split_len;          // multiple of 32
+    const long long pbeg = (long long)blockIdx.x * p.split_len;          // multiple of 32
     long long pend = pbeg + p.split_len;
     if (pend > p.Ptot) pend = p.Ptot;                                    // Ptot is a multiple of 32 too
     const int nchunks = pbeg < pend ? (int)((pend - pbeg) >> 5) : 0;
@@ -228,7 +228,7 @@ bool hc_wgrad_row_ok(const WgradP& p) {
 template <int WRW, int RT, int CTL>
 static void launch_row(const WgradP& p, hipStream_t st) {
     constexpr int BM = WRW * RT * 16, BN = (4 / WRW) * CTL * 16;
-    dim3 grid(p.mz * p.nact + ((p.Cout + BM - 1) / BM - p.mz) * p.nt, p.nslots > 1 ? 2 : 1, p.nsplit);
+    dim3 grid(p.nsplit, p.nslots > 1 ? 2 : 1, p.mz * p.nact + ((p.Cout + BM - 1) / BM - p.mz) * p.nt);
     if (p.KH == 3) hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 3, 3>), grid, dim3(256), 0, st, p);
     else if (p.KW == 3) hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 3>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 1>), grid, dim3(256), 0, st, p);
