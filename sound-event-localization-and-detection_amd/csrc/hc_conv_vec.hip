@@ -36,10 +36,9 @@ typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 // 0.5/d away from an integer, far more than the 2^-23 relative rounding error); ~5 instructions instead of ~30.
 __device__ __forceinline__ int small_div(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
 
-template <int CT, int PT, int KH_T, int KW_T, int MODE>
+template <int CT, int PT, int KH_T, int KW_T, int MODE, int KC, int PAIRS>
 __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
-    constexpr int KK = KH_T * KW_T;
-    constexpr int KC = (KK == 9) ? 36 : 24;        // K chunk: whole channels, multiple of 4
+    constexpr int KK = KH_T * KW_T;                // KC: K chunk, whole channels, multiple of 4 (36: 3x3 and 1x3; 24: 1x3 and 1x1)
     constexpr int NG = KC / 4;                     // k-groups of 4 (16-byte pieces of a weight row)
     constexpr int NS = NG / 4;                     // super groups of 16 k
     constexpr int NL = NG % 4;                     // left-over k-groups: 1 (b32 reads) or 2 (b64 reads)
@@ -73,14 +72,11 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
         const float* wp_ = tid < 8 ? p.w.p[tid] : p.w2.p[tid - 8];
         wdelta_s[tid] = wp_ ? (unsigned)((const char*)wp_ - (const char*)p.wmin) : 0u;
     }
-    // Two convolutions in one launch (ConvP::nslots): the K loop runs over slot 0's weights (and, data gradient,
-    // source), then slot 1's.  A data-gradient workgroup sums both into one result; a forward workgroup writes slot
-    // 0's result after the first pass (the stores drain while the second pass computes) and slot 1's at the end.
-    constexpr bool PAIRS = (KH_T == 1);            // only the 1-D layers come in pairs; the 3x3 kernels have no
-                                                   // registers to spare for the second pass
+    // PAIRS (data gradient only): dst = dgrad(src, w) + dgrad(src2, w2) -- the K loop runs over slot 0's source and
+    // weights, then slot 1's.  A separate instantiation: the extra state costs the single-convolution kernels 10 %.
+    static_assert(!PAIRS || MODE == MODE_DGRAD, "pairs are summed data gradients");
     const int zslot = 0;
-    const int kslots = (PAIRS && p.nslots > 1) ? 2 : 1;
-    const bool fwd_pair = (MODE == MODE_FWD) && kslots > 1;
+    const int kslots = PAIRS ? 2 : 1;
     int wslot = zslot;                             // weight set the next chunk to load belongs to
 
     // ---- buffer descriptor of the streamed operand: based one image before the tile's first image so that the
@@ -216,7 +212,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     bool comp_switch = true;
     auto load_chunk = [&](auto edgec) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edgec)::value;
-        if (lc == nchunks && wslot + 1 < kslots) {
+        if (PAIRS && lc == nchunks && wslot == 0) {
             // data gradient of a pair: the first slot's K range is exhausted, go on with the second source / weights
             wslot = 1;
             lc = 0;
@@ -458,44 +454,27 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     // (data gradient of a pair: the chunk ranges are simply run again for the second source; load_chunk's state
     // machine switches descriptor and weights by itself.  Written as straight-line repeats, not as a loop over the
     // slots: the nested loop cost the 12-tile kernels 100+ VGPRs.)
-    auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < PT; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    };
     auto run_all = [&](auto edgec) __attribute__((always_inline)) {
         if (mixed_wg) {
             const int csplit = (half_k - kbeg) / KC;          // first chunk of the upper K half
             if (p.skip_mode == 1) {                           // forward: primal tiles (lower half) see zeros there
                 run_chunks(0, csplit, IC0{}, ICT{}, edgec);
                 run_chunks(csplit, nchunks, ICH{}, ICT{}, edgec);
-                if (fwd_pair) {
-                    epilogue(0);
-                    zero_acc();
-                    run_chunks(0, csplit, IC0{}, ICT{}, edgec);
-                    run_chunks(csplit, nchunks, ICH{}, ICT{}, edgec);
-                }
             } else {                                          // dgrad: dual tiles (upper half) see zeros in the lower K half
                 run_chunks(0, csplit, IC0{}, ICH{}, edgec);
                 run_chunks(csplit, nchunks, IC0{}, ICT{}, edgec);
-                if (kslots > 1) {
+                if (PAIRS) {
                     run_chunks(0, csplit, IC0{}, ICH{}, edgec);
                     run_chunks(csplit, nchunks, IC0{}, ICT{}, edgec);
                 }
             }
-        } else if (fwd_pair) {
-            run_chunks(0, nchunks, IC0{}, ICT{}, edgec);
-            epilogue(0);
-            zero_acc();
-            run_chunks(0, nchunks, IC0{}, ICT{}, edgec);
         } else {
             run_chunks(0, kslots * nchunks, IC0{}, ICT{}, edgec);
         }
     };
     if (edge_wg) run_all(ETrue{});
     else run_all(EFalse{});
-    epilogue(fwd_pair ? 1 : 0);
+    epilogue(0);
 
 }
 
@@ -503,31 +482,34 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
 int hc_conv_vec_chunk(const ConvP& p, int mode, int ct, int pt) {
     if (getenv("SELD_CONV_NOVEC")) return 0;
     if (!(ct == 12 || ct == 6) || pt != 1) return 0;
-    if (p.nslots > 1 && p.KH != 1) return 0;                   // pairs: 1-D layers only
-    if (p.nslots > 1 && ((p.epilogue | p.epilogue2) & SELD_EPI_STATS)) return 0;   // statistics scratch is the staged chunk
+    if (p.nslots > 1 && (p.KH != 1 || mode != MODE_DGRAD)) return 0;   // pairs: summed data gradients of 1-D layers
     if (!(mode == MODE_FWD || p.wt)) return 0;
     if (p.SDh != 1 || p.SDw != 1 || p.SMh != 1 || p.SMw != 1) return 0;
     if (p.dstW % 4 != 0) return 0;
     const bool t11 = p.KH == 1 && p.KW == 1, t13 = p.KH == 1 && p.KW == 3, t33 = p.KH == 3 && p.KW == 3;
     if (!(t11 || t13 || t33)) return 0;
-    const int kc = t33 ? 36 : 24;
     const int ck = (mode == MODE_FWD ? p.IA : p.OA) * p.KH * p.KW;
-    if (ck % kc != 0) return 0;
-    return kc;
+    if (t33) return ck % 36 == 0 ? 36 : 0;          // (36-deep chunks on the 1x3 layers: measured 15 % slower forward)
+    return ck % 24 == 0 ? 24 : 0;
+    return 0;
 }
 
 template <int CT, int MODE>
 static void launch_vec(const ConvP& p, hipStream_t st) {
     constexpr int BC = CT * 16, BP = 64;
     dim3 grid((unsigned)((p.Ptot + BP - 1) / BP), (unsigned)((p.Cdst + BC - 1) / BC), 1);
-    if (p.KH == 3) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 3, 3, MODE>), grid, dim3(256), 0, st, p);
-    else if (p.KW == 3) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 3, MODE>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 1, MODE>), grid, dim3(256), 0, st, p);
+    constexpr int DG = (MODE == MODE_DGRAD) ? 1 : 0;
+    if (p.KH == 3) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 3, 3, MODE, 36, 0>), grid, dim3(256), 0, st, p);
+    else if (DG && p.nslots > 1 && p.KW == 3) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 3, MODE, 24, DG>), grid, dim3(256), 0, st, p);
+    else if (DG && p.nslots > 1) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 1, MODE, 24, DG>), grid, dim3(256), 0, st, p);
+    else if (p.KW == 3) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 3, MODE, 24, 0>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 1, MODE, 24, 0>), grid, dim3(256), 0, st, p);
 }
 
 // Launches when eligible (returns 1), otherwise returns 0 and the caller falls back to hc_conv_kernel.
 int hc_conv_vec_try(const ConvP& p_in, int mode, int ct, int pt, hipStream_t st) {
-    if (!hc_conv_vec_chunk(p_in, mode, ct, pt)) return 0;
+    const int kc = hc_conv_vec_chunk(p_in, mode, ct, pt);
+    if (!kc) return 0;
     ConvP p = p_in;
     p.pairing = getenv("SELD_VEC_DBG") ? atoi(getenv("SELD_VEC_DBG")) : 0;
     // the component tensors are addressed as wmin + 32-bit byte offset: they must lie within 4 GB of each other

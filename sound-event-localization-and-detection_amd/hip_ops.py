@@ -69,6 +69,8 @@ class _Timed:
             lab = _label_cache.get(key)
             if lab is None:
                 lab = _label_cache[key] = _label(desc, which)
+            if mult == 2 and which == 1 and lab.endswith(", 0>"):
+                lab = lab[:-4] + ", 1>"
             self.on = lab in kernel_timer.only
         if self.on:
             self.desc, self.which = desc, which
@@ -84,7 +86,10 @@ class _Timed:
         if self.on:
             self.e1.record()
             fl, by = conv_work(self.desc, self.which)
-            kernel_timer.records.append((_label(self.desc, self.which), self.e0, self.e1, fl * self.mult, by * self.mult))
+            lab = _label(self.desc, self.which)
+            if self.mult == 2 and self.which == 1 and lab.endswith(", 0>"):
+                lab = lab[:-4] + ", 1>"        # the pair instantiation of the data-gradient kernel
+            kernel_timer.records.append((lab, self.e0, self.e1, fl * self.mult, by * self.mult))
         return False
 
 

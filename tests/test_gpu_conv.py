@@ -169,10 +169,8 @@ def test_conv_pair_matches_two_single_calls(algebra, shape, cout, k, pad, dil, a
     H, L = seld_amd.hip_ops, seld_amd._lib
     kk = (k,) if isinstance(k, int) else k
     desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
-    if len(shape) == 3:        # 1-D layers take the pair kernels; 2-D ones fall back to the single calls (fwd, dgrad)
-        assert all(H._pair_ok(desc, w) for w in (0, 1, 2))
-    else:
-        assert not H._pair_ok(desc, 0) and not H._pair_ok(desc, 1) and H._pair_ok(desc, 2)
+    assert H._pair_ok(desc, 0) and H._pair_ok(desc, 2)
+    assert H._pair_ok(desc, 1) == (len(shape) == 3)      # summed data gradient: 1-D layers; 2-D falls back to two calls
     gen = torch.Generator().manual_seed(99)
     dev = torch.device("cuda:0")
     wshape = (cout // algebra, shape[1] // algebra) + tuple(kk)
