@@ -48,6 +48,39 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
     }
 }
 
+// Same for pooling along H only (pw == 1, the SELD CNN stages) and W a multiple of 4: a thread owns 4 adjacent
+// columns, every access is 16 bytes.
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_v4_kernel(const float* __restrict__ y, PoolGeom g,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  float* __restrict__ pooled, uint8_t* __restrict__ idx) {
+    const int ow = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (ow >= g.OW) return;
+    const int oh = blockIdx.y;
+    const long long nc = blockIdx.z;
+    const int c = (int)(nc % g.C);
+    const long long i = (nc * g.OH + oh) * g.OW + ow;
+    const float a = gamma[c] * invstd[c];
+    const float b = beta[c] - mean[c] * a;
+    const float* base = y + ((size_t)nc * g.H + (size_t)oh * g.ph) * g.W + ow;
+    float best[4] = {0.f, 0.f, 0.f, 0.f};
+    int bi[4] = {0, 0, 0, 0};
+    for (int r = 0; r < g.ph; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * g.W);
+        const float zz[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float z = zz[e] * a + b;
+            z = z > 0.f ? z : 0.f;
+            if (r == 0 || z > best[e] || z != z) { best[e] = z; bi[e] = r; }
+        }
+    }
+    *reinterpret_cast<float4*>(pooled + i) = make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<uchar4*>(idx + i) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+}
+
 // red[c] += sum dz * xhat, red[C + c] += sum dz   over the pooled elements of channel c
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const float* __restrict__ dpooled,
                                                                       const float* __restrict__ pooled, int N, int C,
@@ -139,6 +172,45 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_kernel(const float
     }
 }
 
+// pw == 1, W % 4 == 0, H % ph == 0: 4 adjacent columns per thread, 16-byte accesses
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_v4_kernel(const float* __restrict__ dpooled,
+                                                                        const float* __restrict__ pooled,
+                                                                        const uint8_t* __restrict__ idx,
+                                                                        const float* __restrict__ y, PoolGeom g,
+                                                                        const float* __restrict__ mean,
+                                                                        const float* __restrict__ invstd,
+                                                                        const float* __restrict__ gamma,
+                                                                        const float* __restrict__ red, float inv_count,
+                                                                        int train, float* __restrict__ dy) {
+    const int ow = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (ow >= g.OW) return;
+    const int oh = blockIdx.y;
+    const long long nc = blockIdx.z;
+    const int c = (int)(nc % g.C);
+    const float mu = mean[c], is = invstd[c];
+    const float a = gamma[c] * is;
+    const float k1 = train ? red[g.C + c] * inv_count : 0.f;
+    const float k2 = train ? red[c] * inv_count : 0.f;
+    // dy = a * (d - k1 - (y - mu) * is * k2) = y * c1 + d * a + c0
+    const float c1 = -a * is * k2, c0 = a * (mu * is * k2 - k1);
+    const size_t o = ((size_t)nc * g.OH + oh) * g.OW + ow;
+    const float4 pz = *reinterpret_cast<const float4*>(pooled + o);
+    const float4 dp = *reinterpret_cast<const float4*>(dpooled + o);
+    const uchar4 am = *reinterpret_cast<const uchar4*>(idx + o);
+    const float dz[4] = {pz.x > 0.f ? dp.x : 0.f, pz.y > 0.f ? dp.y : 0.f, pz.z > 0.f ? dp.z : 0.f, pz.w > 0.f ? dp.w : 0.f};
+    const int ai[4] = {am.x, am.y, am.z, am.w};
+    const size_t base = ((size_t)nc * g.H + (size_t)oh * g.ph) * g.W + ow;
+    for (int r = 0; r < g.ph; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(y + base + (size_t)r * g.W);
+        float4 out;
+        out.x = v.x * c1 + (ai[0] == r ? dz[0] * a : 0.f) + c0;
+        out.y = v.y * c1 + (ai[1] == r ? dz[1] * a : 0.f) + c0;
+        out.z = v.z * c1 + (ai[2] == r ? dz[2] * a : 0.f) + c0;
+        out.w = v.w * c1 + (ai[3] == r ? dz[3] * a : 0.f) + c0;
+        *reinterpret_cast<float4*>(dy + base + (size_t)r * g.W) = out;
+    }
+}
+
 static inline unsigned grid_cap(long long items) {
     long long b = (items + 255) / 256;
     if (b < 1) b = 1;
@@ -163,8 +235,12 @@ extern "C" int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32
     int rc = mk_geom(g, N, C, H, W, ph, pw);
     if (rc) return rc;
     if (!y || !mean || !invstd || !gamma || !beta || !pooled || !idx) return SELD_EINVAL;
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((g.OW + 255) / 256, g.OH, (unsigned)g.NC), dim3(256), 0, (hipStream_t)stream, y, g,
-                       mean, invstd, gamma, beta, pooled, idx);
+    if (pw == 1 && W % 4 == 0)
+        hipLaunchKernelGGL(bn_relu_pool_fwd_v4_kernel, dim3((g.OW / 4 + 127) / 128, g.OH, (unsigned)g.NC), dim3(128), 0,
+                           (hipStream_t)stream, y, g, mean, invstd, gamma, beta, pooled, idx);
+    else
+        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((g.OW + 255) / 256, g.OH, (unsigned)g.NC), dim3(256), 0, (hipStream_t)stream, y, g,
+                           mean, invstd, gamma, beta, pooled, idx);
     return check_launch();
 }
 
@@ -184,7 +260,11 @@ extern "C" int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, 
     rc = check_launch();
     if (rc) return rc;
     const int OHx = (H + ph - 1) / ph, OWx = (W + pw - 1) / pw;
-    hipLaunchKernelGGL(bn_relu_pool_bwd_apply_kernel, dim3((OWx + 255) / 256, OHx, (unsigned)g.NC), dim3(256), 0, st, dpooled, pooled, idx, y,
-                       g, mean, invstd, gamma, red, 1.0f / (float)((long long)N * H * W), train, dy);
+    if (pw == 1 && W % 4 == 0 && H % ph == 0)
+        hipLaunchKernelGGL(bn_relu_pool_bwd_apply_v4_kernel, dim3((g.OW / 4 + 127) / 128, g.OH, (unsigned)g.NC), dim3(128), 0, st,
+                           dpooled, pooled, idx, y, g, mean, invstd, gamma, red, 1.0f / (float)((long long)N * H * W), train, dy);
+    else
+        hipLaunchKernelGGL(bn_relu_pool_bwd_apply_kernel, dim3((OWx + 255) / 256, OHx, (unsigned)g.NC), dim3(256), 0, st, dpooled, pooled, idx, y,
+                           g, mean, invstd, gamma, red, 1.0f / (float)((long long)N * H * W), train, dy);
     return check_launch();
 }
