@@ -290,7 +290,7 @@ class HyperConvPairFn(torch.autograd.Function):
     (seld_hc_conv_pair_*).  Falls back to the single entry points per direction when a shape does not qualify."""
 
     @staticmethod
-    def forward(ctx, x, biasA, biasB, addA, addB, stride, padding, dilation, algebra, *ws):
+    def forward(ctx, x, biasA, biasB, addA, addB, stride, padding, dilation, algebra, statsA, statsB, *ws):
         wsA, wsB = ws[:algebra], ws[algebra:]
         k = tuple(wsA[0].shape[2:])
         desc = make_conv_desc(tuple(x.shape), wsA[0].shape[0] * algebra, algebra, k, stride, padding, dilation)
@@ -298,17 +298,17 @@ class HyperConvPairFn(torch.autograd.Function):
         o = conv_out_shape(desc)
         yA = torch.empty(_y_shape(desc, o), device=x.device, dtype=torch.float32)
         yB = torch.empty_like(yA)
-        epiA = L.SELD_EPI_ADD if addA is not None else 0
-        epiB = L.SELD_EPI_ADD if addB is not None else 0
+        epiA = (L.SELD_EPI_ADD if addA is not None else 0) | (L.SELD_EPI_STATS if statsA is not None else 0)
+        epiB = (L.SELD_EPI_ADD if addB is not None else 0) | (L.SELD_EPI_STATS if statsB is not None else 0)
         with _Timed(desc, 0, 2):
             rc = L.lib().seld_hc_conv_pair_fwd(
                 ctypes.byref(desc), L.ptr(x), L.ptr_array8([_req(w, "w") for w in wsA]),
                 L.ptr_array8([_req(w, "w") for w in wsB]), L.ptr(_req(biasA, "bias")), L.ptr(_req(biasB, "bias")),
                 L.ptr(yA), L.ptr(yB), ctypes.c_int32(epiA), ctypes.c_int32(epiB), L.ptr(_req(addA, "addend")),
-                L.ptr(_req(addB, "addend")), None, None, L.current_stream())
+                L.ptr(_req(addB, "addend")), L.ptr(statsA), L.ptr(statsB), L.current_stream())
         if rc == -4:       # SELD_EUNSUPPORTED: e.g. the two weight sets lie more than 4 GB apart
-            conv_fwd(desc, x, wsA, biasA, out=yA, epilogue=epiA, addend=addA)
-            conv_fwd(desc, x, wsB, biasB, out=yB, epilogue=epiB, addend=addB)
+            conv_fwd(desc, x, wsA, biasA, out=yA, epilogue=epiA, addend=addA, stats=statsA)
+            conv_fwd(desc, x, wsB, biasB, out=yB, epilogue=epiB, addend=addB, stats=statsB)
         else:
             L.check(rc, "seld_hc_conv_pair_fwd")
         ctx.desc, ctx.algebra = desc, algebra
@@ -338,7 +338,7 @@ class HyperConvPairFn(torch.autograd.Function):
             else:
                 dx = conv_bwd_data(desc, dyA, wsA, tuple(x.shape))
                 dx += conv_bwd_data(desc, dyB, wsB, tuple(x.shape))
-        need_w = any(ctx.needs_input_grad[9:]) or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        need_w = any(ctx.needs_input_grad[11:]) or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dwsA, dwsB, dbA, dbB = [None] * A, [None] * A, None, None
         if need_w:
             dirA, dirB = _direct_targets(wsA, biasA), _direct_targets(wsB, biasB)
@@ -360,25 +360,30 @@ class HyperConvPairFn(torch.autograd.Function):
                         else:
                             dwsB, dbB = g, gb
         return (dx, dbA, dbB, dyA if ctx.needs_input_grad[3] else None, dyB if ctx.needs_input_grad[4] else None,
-                None, None, None, None, *dwsA, *dwsB)
+                None, None, None, None, None, None, *dwsA, *dwsB)
 
 
-def hyper_conv_pair(x, wsA, biasA, wsB, biasB, stride, padding, dilation, addA=None, addB=None):
-    """Two convolutions of the same input.  One launch when both have the same shape and the kernels support the
-    pair form for it; otherwise exactly the two single calls."""
+def hyper_conv_pair(x, wsA, biasA, wsB, biasB, stride, padding, dilation, addA=None, addB=None, statsA=None, statsB=None):
+    """Two convolutions of the same input.  One call when both have the same shape (and one launch per direction
+    where the kernels support the pair form); otherwise exactly the two single calls.  statsA / statsB: zeroed
+    statistics buffers (`new_stats`) to receive the BatchNorm batch statistics of the two results."""
     same = (len(wsA) == len(wsB) and tuple(wsA[0].shape) == tuple(wsB[0].shape) and
             (biasA is None) == (biasB is None) and x.is_cuda)
     if same:
         k = tuple(wsA[0].shape[2:])
         desc = make_conv_desc(tuple(x.shape), wsA[0].shape[0] * len(wsA), len(wsA), k, stride, padding, dilation)
         if _pair_ok(desc, 0):
-            return HyperConvPairFn.apply(x, biasA, biasB, addA, addB, stride, padding, dilation, len(wsA), *wsA, *wsB)
+            return HyperConvPairFn.apply(x, biasA, biasB, addA, addB, stride, padding, dilation, len(wsA), statsA, statsB,
+                                         *wsA, *wsB)
 
-    def one(ws, bias, add):
-        if add is None:
-            return hyper_conv(x, ws, bias, stride, padding, dilation)
-        return hyper_conv_add(x, ws, bias, add, stride, padding, dilation)
-    return one(wsA, biasA, addA), one(wsB, biasB, addB)
+    def one(ws, bias, add, stats):
+        y = hyper_conv(x, ws, bias, stride, padding, dilation) if add is None else \
+            hyper_conv_add(x, ws, bias, add, stride, padding, dilation)
+        if stats is not None:
+            N, C, S = _ncs(y)
+            L.check(L.lib().seld_channel_stats(L.ptr(y), N, C, S, L.ptr(stats), L.current_stream()), "seld_channel_stats")
+        return y
+    return one(wsA, biasA, addA, statsA), one(wsB, biasB, addB, statsB)
 
 
 # ======================================================================================
@@ -410,9 +415,9 @@ def new_stats(C, device):
     return t
 
 
-def channel_stats(x):
+def channel_stats(x, out=None):
     N, C, S = _ncs(x)
-    stats = new_stats(C, x.device)
+    stats = out if out is not None else new_stats(C, x.device)
     L.check(L.lib().seld_channel_stats(L.ptr(x), N, C, S, L.ptr(stats), L.current_stream()), "seld_channel_stats")
     return stats
 
@@ -523,11 +528,12 @@ class GateFn(torch.autograd.Function):
     """y = tanh(BN_f(yf)) * sigmoid(BN_g(yg)) * channel_mask  (model.py:121-128)."""
 
     @staticmethod
-    def forward(ctx, yf, yg, gf, bf, rmf, rvf, gg, bg, rmg, rvg, training, momentum, eps, mask, nbt_f, nbt_g):
+    def forward(ctx, yf, yg, gf, bf, rmf, rvf, gg, bg, rmg, rvg, training, momentum, eps, mask, nbt_f, nbt_g,
+                stats_f=None, stats_g=None):
         yf, yg = _req(yf, "yf"), _req(yg, "yg")
         N, C, S = _ncs(yf)
-        mf, isf = bn_prepare(yf, rmf, rvf, training, momentum, eps, None, nbt_f)
-        mg, isg = bn_prepare(yg, rmg, rvg, training, momentum, eps, None, nbt_g)
+        mf, isf = bn_prepare(yf, rmf, rvf, training, momentum, eps, stats_f, nbt_f)
+        mg, isg = bn_prepare(yg, rmg, rvg, training, momentum, eps, stats_g, nbt_g)
         y = torch.empty_like(yf)
         L.check(L.lib().seld_gate_fwd(L.ptr(yf), L.ptr(yg), N, C, S, L.ptr(mf), L.ptr(isf), L.ptr(gf), L.ptr(bf),
                                       L.ptr(mg), L.ptr(isg), L.ptr(gg), L.ptr(bg), L.ptr(mask), L.ptr(y),
@@ -558,15 +564,16 @@ class GateFn(torch.autograd.Function):
         if slot is not None:
             if not clean:
                 axpy_(slot, red, 4 * C)
-            return (dyf, dyg) + (None,) * 14
+            return (dyf, dyg) + (None,) * 16
         return (dyf, dyg, red[:C], red[C:2 * C], None, None, red[2 * C:3 * C], red[3 * C:], None, None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
-def gate(yf, yg, bn_f, bn_g, mask=None):
+def gate(yf, yg, bn_f, bn_g, mask=None, stats_f=None, stats_g=None):
     return GateFn.apply(yf, yg, bn_f.weight, bn_f.bias, bn_f.running_mean, bn_f.running_var,
                         bn_g.weight, bn_g.bias, bn_g.running_mean, bn_g.running_var, bn_f.training,
-                        bn_f.momentum if bn_f.momentum is not None else 0.1, bn_f.eps, mask, _nbt(bn_f), _nbt(bn_g))
+                        bn_f.momentum if bn_f.momentum is not None else 0.1, bn_f.eps, mask, _nbt(bn_f), _nbt(bn_g),
+                        stats_f, stats_g)
 
 
 # ======================================================================================
@@ -896,7 +903,7 @@ def gate_plain(yf, yg, mask=None):
         _identity_cache[key] = (torch.zeros(C, device=yf.device), torch.ones(C, device=yf.device))
     zero, one = _identity_cache[key]
 
-    return GateFn.apply(yf, yg, one, zero, zero, one, one, zero, zero, one, False, 0.1, 0.0, mask, None, None)
+    return GateFn.apply(yf, yg, one, zero, zero, one, one, zero, zero, one, False, 0.1, 0.0, mask, None, None, None, None)
 
 
 # ======================================================================================

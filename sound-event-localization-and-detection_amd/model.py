@@ -122,36 +122,49 @@ class ResBlock(nn.Module):
             return H.hyper_conv(x, _components(conv), conv.bias, s, p, d)
         return H.hyper_conv_add(x, _components(conv), conv.bias, addend, s, p, d)
 
-    def _conv_pair(self, conv_a, conv_b, x, add_a=None, add_b=None):
-        """Two convolutions of the same input: one launch when they share the geometry (hip_ops.hyper_conv_pair)."""
+    def _conv_pair(self, conv_a, conv_b, x, add_a=None, add_b=None, stats_a=None, stats_b=None):
+        """Two convolutions of the same input: one call when they share the geometry (hip_ops.hyper_conv_pair)."""
         ga, gb = _geom(conv_a), _geom(conv_b)
-        if ga != gb:
-            return self._conv(conv_a, x, add_a), self._conv(conv_b, x, add_b)
         s, p, d = ga
+        if ga != gb:
+            ya, yb = self._conv(conv_a, x, add_a), self._conv(conv_b, x, add_b)
+            for y_, st_ in ((ya, stats_a), (yb, stats_b)):
+                if st_ is not None:
+                    H.channel_stats(y_, st_)
+            return ya, yb
         return H.hyper_conv_pair(x, _components(conv_a), conv_a.bias, _components(conv_b), conv_b.bias, s, p, d,
-                                 add_a, add_b)
+                                 add_a, add_b, stats_a, stats_b)
 
-    def fused(self, x, skip_sum=None, need_residual=True):
-        """Returns (x_hat + conv2_residual(y)  or None, skip_sum + conv2_skip(y))."""
+    def fused(self, x, skip_sum=None, need_residual=True, x_stats=None, want_res_stats=False):
+        """Returns (x_hat + conv2_residual(y)  or None, skip_sum + conv2_skip(y), statistics of the residual or None).
+        The BatchNorm batch statistics of a convolution's result are gathered by that convolution's epilogue:
+        x_stats are those of this block's input (from the previous block), the returned ones go to the next block."""
         bn = self.batch_norm in _TCN_BN
+        train_stats = bn and self.training
         if bn:
-            x = H.bn_act(x, self.batch_filter1, L.SELD_ACT_TANH)
-        yf, yg = self._conv_pair(self.conv1_filter, self.conv1_gate, x)
+            x = H.bn_act(x, self.batch_filter1, L.SELD_ACT_TANH, x_stats if self.batch_filter1.training else None)
+        st_f = H.new_stats(self.batch_filter2.num_features, x.device) if train_stats else None
+        st_g = H.new_stats(self.batch_gate2.num_features, x.device) if train_stats else None
+        yf, yg = self._conv_pair(self.conv1_filter, self.conv1_gate, x, None, None, st_f, st_g)
         mask = None
         if self.training and not self.spatial_dropout_rate == 0:
             mask = H.channel_dropout_mask(yf.shape[0], yf.shape[1], self.spatial_dropout_rate, yf.device)
         if bn:
-            y = H.gate(yf, yg, self.batch_filter2, self.batch_gate2, mask)
+            y = H.gate(yf, yg, self.batch_filter2, self.batch_gate2, mask, st_f, st_g)
         else:
             y = H.gate_plain(yf, yg, mask)
+        res_stats = None
         if need_residual:
-            skip, res = self._conv_pair(self.conv2_skip, self.conv2_residual, y, skip_sum, x)
+            if want_res_stats and train_stats:
+                res_stats = H.new_stats(self.batch_filter1.num_features, x.device)
+            skip, res = self._conv_pair(self.conv2_skip, self.conv2_residual, y, skip_sum, x, None, res_stats)
         else:
             skip, res = self._conv(self.conv2_skip, y, skip_sum), None
-        return res, skip
+        return res, skip, res_stats
 
     def forward(self, x):
-        return self.fused(x, None, True)
+        res, skip, _ = self.fused(x, None, True)
+        return res, skip
 
 
 class TC_Block(nn.Module):
@@ -204,8 +217,10 @@ class TC_Block(nn.Module):
     def forward(self, residual):
         skip = None
         last = len(self.ResBlocks) - 1
+        stats = None                     # batch statistics of `residual`, gathered by the convolution that wrote it
         for i, blk in enumerate(self.ResBlocks):
-            residual, skip = blk.fused(residual, skip, need_residual=i < last)
+            residual, skip, stats = blk.fused(residual, skip, need_residual=i < last, x_stats=stats,
+                                              want_res_stats=i < last)
         out = self.relu1(skip)
         if self.pool_time == 'TCN':
             out = self.maxpool1(out)
