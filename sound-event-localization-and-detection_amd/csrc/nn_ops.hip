@@ -86,22 +86,27 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
     block_atomic<2>(v, dst);
 }
 
-__global__ void bn_finalize_kernel(float* __restrict__ stats, int C, double count, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ rmean, float* __restrict__ rvar,
-                                   long long* __restrict__ nbt, int clear) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;                          // num_batches_tracked (torch.nn.BatchNorm bookkeeping)
+// One WAVE per channel: lane r owns replica row r (SELD_STATS_REPLICAS == 64), the 64 partial sums are added in fp64
+// with a shuffle tree.  (A thread per channel walking the 64 rows took 8 us -- per BatchNorm, 33 times a step.)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ stats, int C, double count, float eps,
+                                                          float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ invstd, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, long long* __restrict__ nbt, int clear) {
+    static_assert(SELD_STATS_REPLICAS == 64, "one lane per replica row");
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;      // num_batches_tracked (torch.nn.BatchNorm bookkeeping)
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < SELD_STATS_REPLICAS; ++r) {
-        s1 += (double)stats[(size_t)r * 2 * C + c];
-        s2 += (double)stats[(size_t)r * 2 * C + C + c];
-        if (clear) {                                       // hand the buffer back zeroed (pooled by the host mirror)
-            stats[(size_t)r * 2 * C + c] = 0.f;
-            stats[(size_t)r * 2 * C + C + c] = 0.f;
-        }
+    float* p1 = stats + (size_t)lane * 2 * C + c;
+    float* p2 = p1 + C;
+    double s1 = (double)*p1, s2 = (double)*p2;
+    if (clear) { *p1 = 0.f; *p2 = 0.f; }                              // hand the buffer back zeroed (pooled by the host mirror)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
     }
+    if (lane != 0) return;
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -626,7 +631,7 @@ extern "C" int seld_bn_finalize_ex(float* stats, int32_t C, int64_t count, float
                                    float* invstd, float* running_mean, float* running_var,
                                    int64_t* num_batches_tracked, int32_t clear_stats, void* stream) {
     if (!stats || !mean || !invstd || C <= 0 || count <= 0) return SELD_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), stats, C, (double)count, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, ST(stream), stats, C, (double)count, eps,
                        momentum, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, clear_stats);
     return check_launch();
 }
