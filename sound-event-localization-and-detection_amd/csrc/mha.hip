@@ -287,6 +287,13 @@ static int launch_bwd(const float* q, const float* k, const float* v, const floa
     return check_launch();
 }
 
+// fp32-MFMA kernels for head dims 16/32/48/64 and T % 16 == 0 (mha_mfma.hip)
+bool mha_mfma_ok(int T, int hd);
+int mha_mfma_fwd(const float* q, const float* k, const float* v, int N, int T, int H, int hd, float* out, float* lse,
+                 hipStream_t st);
+int mha_mfma_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
+                 int N, int T, int H, int hd, float* dq, float* dk, float* dv, hipStream_t st);
+
 }  // namespace seld
 using namespace seld;
 
@@ -294,6 +301,7 @@ extern "C" int seld_mha_fwd(const float* q, const float* k, const float* v, int3
                             float* out, float* lse, void* stream) {
     if (!q || !k || !v || !out || !lse || N <= 0 || T <= 0 || H <= 0 || hd <= 0) return SELD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (mha_mfma_ok(T, hd)) return mha_mfma_fwd(q, k, v, N, T, H, hd, out, lse, st);
     if (hd <= 8) return launch_fwd<8>(q, k, v, N, T, H, hd, out, lse, st);
     if (hd <= 16) return launch_fwd<16>(q, k, v, N, T, H, hd, out, lse, st);
     if (hd <= 32) return launch_fwd<32>(q, k, v, N, T, H, hd, out, lse, st);
@@ -318,6 +326,7 @@ extern "C" int seld_mha_bwd(const float* q, const float* k, const float* v, cons
     hipLaunchKernelGGL(mha_delta_kernel, dim3((T + 255) / 256, N * H), dim3(256), 0, st, out, dout, T, H, hd, delta);
     int rc = check_launch();
     if (rc) return rc;
+    if (mha_mfma_ok(T, hd)) return mha_mfma_bwd(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);
     if (hd <= 8) return launch_bwd<8>(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);
     if (hd <= 16) return launch_bwd<16>(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);
     if (hd <= 32) return launch_bwd<32>(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);

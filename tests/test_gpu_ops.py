@@ -168,10 +168,12 @@ def test_mha_module_matches_fixture(golden):
     _close(mha.fc_out.bias.grad, g["dbo"], rel=5e-4, what="dbo")
 
 
-@pytest.mark.parametrize("N,H_,hd,T", [(2, 8, 48, 256), (1, 8, 16, 100), (1, 4, 64, 130), (2, 8, 2, 33), (1, 2, 48, 600)])
+@pytest.mark.parametrize("N,H_,hd,T", [(2, 8, 48, 256), (1, 8, 16, 100), (1, 4, 64, 130), (2, 8, 2, 33), (1, 2, 48, 600),
+                                       (1, 2, 32, 144), (1, 4, 64, 128), (2, 3, 16, 48), (1, 2, 48, 608)])
 def test_mha_core_vs_sdpa(N, H_, hd, T):
-    """Flash kernel vs torch's scaled_dot_product_attention in fp64 on the CPU, incl. a spiky row that forces
-    the online-softmax rescale across key tiles (guide rule 26)."""
+    """Flash kernels vs torch's scaled_dot_product_attention in fp64 on the CPU, incl. a spiky row that forces
+    the online-softmax rescale across key tiles (guide rule 26).  Head dims 16/32/48/64 with T % 16 == 0 run on the
+    fp32-MFMA kernels (mha_mfma.hip), everything else on the VALU kernels (mha.hip)."""
     H = pkg().hip_ops
     gen = torch.Generator().manual_seed(5)
     E = H_ * hd
