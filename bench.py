@@ -113,9 +113,13 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     pkg = importlib.import_module(PKG)
     H, T, DP = pkg.hip_ops, pkg.train, pkg.dp
-    rank, local, world = DP.init_from_env("nccl")
+    # Rehearsal hooks for a one-GPU box (never set by the driver): SELD_BENCH_BACKEND=gloo with
+    # SELD_BENCH_SINGLE_DEVICE=1 runs every rank on cuda:0 to exercise the multi-process path without RCCL.
+    rank, local, world = DP.init_from_env(os.environ.get("SELD_BENCH_BACKEND", "nccl"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("SELD_BENCH_SINGLE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
