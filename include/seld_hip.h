@@ -193,6 +193,20 @@ int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, const uint8
                           const float* invstd, const float* gamma, const float* beta, int32_t train,
                           float* red, float* dy, void* stream);
 
+/* The same backward for a convolution whose INPUT needs no gradient (the first layer), without ever writing the
+ * gradient w.r.t. the conv output (1.6 GB at batch 32):
+ *   seld_bn_relu_pool_bwd_coef        : the reductions (red = dgamma | dbeta) and coef = [c1 | a | c0] (3C) such that
+ *                                       dy = y*c1 + dz*a + c0; conv_dbias (nullable, C) += sum over positions of dy
+ *   seld_hc_conv_bwd_weight_bnpool_acc: dw[c] += weight gradient, dy formed from y / pooled / dpooled / idx / coef while
+ *                                       the operand is staged (3x3 taps, pooling along H only; else SELD_EUNSUPPORTED) */
+int seld_bn_relu_pool_bwd_coef(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                               int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, int32_t train,
+                               float* red, float* coef, float* conv_dbias /* nullable */, void* stream);
+int seld_hc_conv_bwd_weight_bnpool_acc(const seld_conv_desc* d, const float* x, const float* y, const float* pooled,
+                                       const float* dpooled, const uint8_t* idx, int32_t ph, const float* coef,
+                                       float* const dw[8], void* stream);
+
 /* y = act(gamma * (x - mean) * invstd + beta) */
 int seld_bn_act_fwd(const float* x, int32_t N, int32_t C, int32_t S, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, int32_t act, float* y, void* stream);

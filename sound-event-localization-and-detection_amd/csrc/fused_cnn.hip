@@ -211,6 +211,22 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_v4_kernel(const fl
     }
 }
 
+// coef = [c1 | a | c0] with  dy = y*c1 + dz*a + c0  (the apply kernel's formula, per channel); dbias += sum(dy)
+__global__ void bn_pool_coef_kernel(const float* __restrict__ red, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma, int C,
+                                    float inv_count, int train, float* __restrict__ coef, float* __restrict__ dbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mu = mean[c], is = invstd[c], a = gamma[c] * is;
+    const float k1 = train ? red[C + c] * inv_count : 0.f;
+    const float k2 = train ? red[c] * inv_count : 0.f;
+    coef[c] = -a * is * k2;
+    coef[C + c] = a;
+    coef[2 * C + c] = a * (mu * is * k2 - k1);
+    // sum over positions of dy: a * (sum dz - P*k1 - k2 * sum xhat); with batch statistics both corrections cancel it
+    if (dbias) dbias[c] += train ? 0.f : a * red[C + c];
+}
+
 static inline unsigned grid_cap(long long items) {
     long long b = (items + 255) / 256;
     if (b < 1) b = 1;
@@ -241,6 +257,29 @@ extern "C" int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32
     else
         hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((g.OW + 255) / 256, g.OH, (unsigned)g.NC), dim3(256), 0, (hipStream_t)stream, y, g,
                            mean, invstd, gamma, beta, pooled, idx);
+    return check_launch();
+}
+
+// First half of seld_bn_relu_pool_bwd for a convolution whose INPUT needs no gradient (the first layer): the
+// reductions (red = dgamma | dbeta sums, from pooled-size tensors) and the three per-channel coefficients with which
+// seld_hc_conv_bwd_weight_bnpool_acc forms dy on the fly.  The 1.6 GB gradient w.r.t. the conv output is never written.
+extern "C" int seld_bn_relu_pool_bwd_coef(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                                          int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                                          const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                          int32_t train, float* red, float* coef, float* conv_dbias, void* stream) {
+    PoolGeom g;
+    int rc = mk_geom(g, N, C, H, W, ph, pw);
+    if (rc) return rc;
+    if (!dpooled || !pooled || !idx || !y || !mean || !invstd || !gamma || !beta || !red || !coef) return SELD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = g.OH * g.OW;
+    const long long M = (long long)N * S;
+    hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel, dim3((unsigned)((M + 8191) / 8192), C), dim3(256), 0, st, dpooled, pooled,
+                       N, C, S, gamma, beta, y, idx, g, mean, invstd, red);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_pool_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, mean, invstd, gamma, C,
+                       1.0f / (float)((long long)N * H * W), train, coef, conv_dbias);
     return check_launch();
 }
 

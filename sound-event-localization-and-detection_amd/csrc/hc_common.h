@@ -66,6 +66,14 @@ struct WgradP {
     int nslots;
     const float* dy2;
     WPtrsMut gw2;
+    // Fused BatchNorm+ReLU+MaxPool(ph, 1) backward (hc_wgrad_row_kernel<..., 1>): `dy` is the CONV OUTPUT y and the
+    // gradient is formed while staging:  dy = y*c1[co] + dz*a[co] + c0[co],  dz = dpooled at the arg-max row of a
+    // window whose pooled value is > 0, else 0.  coef = [c1 | a | c0] (3*Cout).
+    const float* pooled;
+    const float* dpooled;
+    const unsigned char* pidx;
+    const float* coef;
+    int poolh;         // pooling window height
     int mz, nact, nt;  // tile enumeration without the zero quadrant: the first mz row tiles have nact column tiles, the rest nt
     int dbg;           // SELD_WGRAD_DBG: timing experiments (wrong results): 1 = no loads in the loop, 2 = no LDS stores
 };

@@ -607,6 +607,40 @@ int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
 }  // namespace seld
 using namespace seld;
 
+// dw[c] += weight gradient of a convolution that is followed by BatchNorm2d -> ReLU -> MaxPool2d(ph, 1) and whose
+// input needs no gradient: the gradient w.r.t. the conv output is formed from y, the pooled-size tensors and `coef`
+// (seld_bn_relu_pool_bwd_coef) while the operand is staged.  SELD_EUNSUPPORTED when the shape does not qualify.
+extern "C" int seld_hc_conv_bwd_weight_bnpool_acc(const seld_conv_desc* d, const float* x, const float* y,
+                                                  const float* pooled, const float* dpooled, const uint8_t* idx,
+                                                  int32_t ph, const float* coef, float* const dw[8], void* stream) {
+    int rc = hc_validate(d);
+    if (rc) return rc;
+    int o[2];
+    hc_out_shape(d, o);
+    if (o[0] <= 0 || o[1] <= 0 || !x || !y || !pooled || !dpooled || !idx || !coef || !dw || ph <= 0) return SELD_EINVAL;
+    if (d->k[0] != 3 || d->k[1] != 3 || o[0] % ph != 0 || (long long)d->Cout * (o[0] / ph) * o[1] >= (1LL << 29))
+        return SELD_EUNSUPPORTED;
+    WgradP p{};
+    p.algebra = d->algebra; p.N = d->N; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.inH = d->in[0]; p.inW = d->in[1]; p.outH = o[0]; p.outW = o[1];
+    p.KH = d->k[0]; p.KW = d->k[1];
+    p.sh = d->stride[0]; p.sw = d->stride[1]; p.ph = d->pad[0]; p.pw = d->pad[1]; p.dh = d->dil[0]; p.dw = d->dil[1];
+    p.Ktot = d->Cin * p.KH * p.KW;
+    p.OA = d->Cout / d->algebra; p.IA = d->Cin / d->algebra;
+    p.inS = p.inH * p.inW; p.outS = p.outH * p.outW;
+    p.Ptot = (long long)d->N * p.outS;
+    p.x = x; p.dy = y;
+    p.nslots = 1;
+    p.pooled = pooled; p.dpooled = dpooled; p.pidx = idx; p.coef = coef; p.poolh = ph;
+    for (int i = 0; i < 8; ++i) p.gw.p[i] = (i < d->algebra) ? dw[i] : nullptr;
+    const int cfg = wgrad_cfg(d);
+    static const int tile_m[5] = {128, 192, 64, 96, 64}, tile_n[5] = {128, 80, 64, 128, 80};
+    p.nsplit = wgrad_splits(d, o, tile_m[cfg], tile_n[cfg], &p);
+    if (!hc_wgrad_row_ok(p)) return SELD_EUNSUPPORTED;
+    hc_wgrad_row_launch(p, cfg, (hipStream_t)stream);
+    return check_launch();
+}
+
 // dwA[c] += wgrad(x, dyA), dwB[c] += wgrad(x, dyB) (+ bias gradients): one launch for two convolutions that read
 // the same input with the same geometry.  SELD_EUNSUPPORTED when the shape does not qualify: call the single form twice.
 extern "C" int seld_hc_conv_pair_bwd_weight_acc(const seld_conv_desc* d, const float* x, const float* dyA,

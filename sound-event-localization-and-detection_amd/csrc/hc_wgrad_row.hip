@@ -25,7 +25,7 @@ namespace seld {
 
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 
-template <int WRW, int RT, int CTL, int KH_T, int KW_T>
+template <int WRW, int RT, int CTL, int KH_T, int KW_T, int FUSED>
 __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
     constexpr int WCW = 4 / WRW;
     constexpr int BM = WRW * RT * 16;
@@ -63,11 +63,21 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
 
     // ---- loop-invariant per-thread offsets (bytes) ------------------------------------------------------------
     unsigned a_voff[AR];
+    // FUSED: the row's offset in the pooled-size tensors and its three BatchNorm-backward coefficients
+    const int pooledS = FUSED ? (p.outH / p.poolh) * p.outW : 0;
+    unsigned p_voff[AR];
+    float c_1[AR], c_a[AR], c_0[AR];
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
         const int r = rsub + 32 * j;
         const bool ok = r < BM && (m0 + r) < p.Cout;
         a_voff[j] = ok ? (unsigned)(((m0 + r) * p.outS + 4 * g) * 4) : OOB;
+        if (FUSED) {
+            p_voff[j] = ok ? (unsigned)((m0 + r) * pooledS + 4 * g) : OOB;        // in ELEMENTS (float and uint8 tensors)
+            c_1[j] = ok ? p.coef[m0 + r] : 0.f;
+            c_a[j] = ok ? p.coef[p.Cout + m0 + r] : 0.f;
+            c_0[j] = ok ? p.coef[2 * p.Cout + m0 + r] : 0.f;
+        }
     }
     // The x descriptor is based (ph rows + pw columns) BEFORE the step's first input element, so that every
     // in-range element has a non-negative offset: column (ci, kh, kw) of position group g sits at
@@ -106,6 +116,9 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
     const int wspan = (KW_T - 1) * p.dw - p.pw;          // last tap's column shift
 
     floatx4 ar[AR], br[BR];
+    floatx4 pz[AR], pd[AR];          // FUSED: pooled activations and their gradient for the step's window row
+    unsigned pi[AR];                 // FUSED: four arg-max bytes
+    int prow = 0;                    // FUSED: row of the step inside its pooling window
 
     // `advance` is false for the prefetch issued during the last step: it re-reads that step (valid addresses) into
     // the LDS buffer nobody reads, so the loop body needs no branch around its loads and stores.
@@ -118,6 +131,24 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
         for (int j = 0; j < AR; ++j) {
             const uintx4 v = __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff[j], 0, 0);
             ar[j] = (floatx4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+        }
+        if (FUSED) {
+            const int qh = t_oh / p.poolh;
+            prow = t_oh - qh * p.poolh;
+            const long long pq = (long long)t_img * p.Cout * pooledS + (long long)qh * p.outW + t_ow;
+            const unsigned nrec_p = (unsigned)((long long)p.Cout * pooledS * 4);
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pooled + pq), 0, nrec_p, 0x00020000);
+            const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dpooled + pq), 0, nrec_p, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pidx + pq), 0, nrec_p / 4, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const unsigned eo = p_voff[j];
+                const uintx4 z = __builtin_amdgcn_raw_buffer_load_b128(zr, eo == OOB ? OOB : eo * 4u, 0, 0);
+                const uintx4 d = __builtin_amdgcn_raw_buffer_load_b128(dr, eo == OOB ? OOB : eo * 4u, 0, 0);
+                pz[j] = (floatx4){__uint_as_float(z[0]), __uint_as_float(z[1]), __uint_as_float(z[2]), __uint_as_float(z[3])};
+                pd[j] = (floatx4){__uint_as_float(d[0]), __uint_as_float(d[1]), __uint_as_float(d[2]), __uint_as_float(d[3])};
+                pi[j] = __builtin_amdgcn_raw_buffer_load_b32(ir, eo, 0, 0);
+            }
         }
         const int ihb = t_oh * p.sh;
         const bool interior = (t_ow - p.pw >= 0) && (t_ow + 31 + wspan < p.inW);      // scalar
@@ -152,7 +183,19 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
     };
     auto store_chunk = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < AR; ++j) *reinterpret_cast<floatx4*>(&As[buf][g][rsub + 32 * j][0]) = ar[j];
+        for (int j = 0; j < AR; ++j) {
+            floatx4 a4 = ar[j];
+            if (FUSED) {
+                // gradient w.r.t. the conv output from the conv output itself and the pooled-size tensors (the
+                // formula of bn_relu_pool_bwd_apply_kernel); rows outside the tensor have all-zero coefficients
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool hit = (pz[j][e] > 0.f) && ((int)((pi[j] >> (8 * e)) & 0xFFu) == prow);
+                    a4[e] = ar[j][e] * c_1[j] + (hit ? pd[j][e] * c_a[j] : 0.f) + c_0[j];
+                }
+            }
+            *reinterpret_cast<floatx4*>(&As[buf][g][rsub + 32 * j][0]) = a4;
+        }
 #pragma unroll
         for (int j = 0; j < BR; ++j) *reinterpret_cast<floatx4*>(&Bs[buf][g][rsub + 32 * j][0]) = br[j];
     };
@@ -229,9 +272,10 @@ template <int WRW, int RT, int CTL>
 static void launch_row(const WgradP& p, hipStream_t st) {
     constexpr int BM = WRW * RT * 16, BN = (4 / WRW) * CTL * 16;
     dim3 grid(p.nsplit, p.nslots > 1 ? 2 : 1, p.mz * p.nact + ((p.Cout + BM - 1) / BM - p.mz) * p.nt);
-    if (p.KH == 3) hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 3, 3>), grid, dim3(256), 0, st, p);
-    else if (p.KW == 3) hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 3>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 1>), grid, dim3(256), 0, st, p);
+    if (p.coef) hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 3, 3, 1>), grid, dim3(256), 0, st, p);   // fused BN/pool backward
+    else if (p.KH == 3) hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 3, 3, 0>), grid, dim3(256), 0, st, p);
+    else if (p.KW == 3) hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 3, 0>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 1, 0>), grid, dim3(256), 0, st, p);
 }
 
 // cfg as in wgrad_cfg(): 0 = 128 x 128, 1 = 192 x 80, 2 = 64 x 64, 3 = 96 x 128, 4 = 64 x 80

@@ -3,6 +3,7 @@
 Everything here requires CUDA(HIP) tensors: fp32, contiguous.  No eager/CPU fallback exists.
 """
 import ctypes
+import os
 
 import torch
 
@@ -983,3 +984,83 @@ def axpy_(dst_first, src, n):
 def bn_relu_pool(y, bn, ph, pw, stats=None):
     return BnReluPoolFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
                               bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(ph), int(pw), stats, _nbt(bn))
+
+class ConvBnReluPoolFn(torch.autograd.Function):
+    """pooled = MaxPool2d(ph, 1)(ReLU(BatchNorm2d(W (x) x))) for a convolution whose INPUT needs no gradient -- the first
+    CNN stage (model.py:269-283 on the network input).  Forward is the same three kernels as hyper_conv_stats +
+    bn_relu_pool.  Backward never writes the gradient w.r.t. the conv output (1.6 GB at batch 32): the per-channel
+    reductions come from pooled-size tensors (seld_bn_relu_pool_bwd_coef) and the weight-gradient kernel forms
+    dy = y*c1 + dz*a + c0 while it stages its operand (seld_hc_conv_bwd_weight_bnpool_acc).  Needs FlatAdam's gradient
+    slots (the kernel accumulates); `conv_bn_relu_pool` falls back to the two separate functions otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, bias, gamma, beta, running_mean, running_var, training, momentum, eps, ph, nbt, stride, padding,
+                dilation, *ws):
+        algebra = len(ws)
+        k = tuple(ws[0].shape[2:])
+        desc = make_conv_desc(tuple(x.shape), ws[0].shape[0] * algebra, algebra, k, stride, padding, dilation)
+        x = _req(x, "x")
+        stats = new_stats(desc.Cout, x.device) if training else None
+        y = conv_fwd(desc, x, ws, bias, epilogue=L.SELD_EPI_STATS if training else 0, stats=stats)
+        N, C, Hh, Ww = y.shape
+        mean, invstd = bn_prepare(y, running_mean, running_var, training, momentum, eps, stats, nbt)
+        pooled = torch.empty((N, C, Hh // ph, Ww), device=y.device, dtype=torch.float32)
+        idx = torch.empty(pooled.shape, device=y.device, dtype=torch.uint8)
+        L.check(L.lib().seld_bn_relu_pool_fwd(L.ptr(y), N, C, Hh, Ww, ph, 1, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                              L.ptr(beta), L.ptr(pooled), L.ptr(idx), L.current_stream()),
+                "seld_bn_relu_pool_fwd")
+        ctx.desc, ctx.geom = desc, (N, C, Hh, Ww, ph, training)
+        ctx.params = (ws, bias, gamma, beta)
+        ctx.save_for_backward(x, y, pooled, idx, mean, invstd)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x, y, pooled, idx, mean, invstd = ctx.saved_tensors
+        ws, bias, gamma, beta = ctx.params
+        N, C, Hh, Ww, ph, training = ctx.geom
+        dpooled = _req(dpooled, "dpooled")
+        direct = _direct_targets(ws, bias)
+        if direct is None:
+            raise L.SeldHipError("ConvBnReluPoolFn needs gradient slots (FlatAdam); use hyper_conv_stats + bn_relu_pool")
+        slot, clean = _claim_grad_slots((gamma, beta))
+        red = slot if clean else torch.zeros(2 * C, device=y.device, dtype=torch.float32)
+        coef = torch.empty(3 * C, device=y.device, dtype=torch.float32)
+        st = L.current_stream()
+        L.check(L.lib().seld_bn_relu_pool_bwd_coef(L.ptr(dpooled), L.ptr(pooled), L.ptr(idx), L.ptr(y), N, C, Hh, Ww, ph, 1,
+                                                   L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(training),
+                                                   L.ptr(red), L.ptr(coef), L.ptr(direct[1]), st),
+                "seld_bn_relu_pool_bwd_coef")
+        with _Timed(ctx.desc, 2):
+            L.check(L.lib().seld_hc_conv_bwd_weight_bnpool_acc(ctypes.byref(ctx.desc), L.ptr(x), L.ptr(y), L.ptr(pooled),
+                                                               L.ptr(dpooled), L.ptr(idx), ph, L.ptr(coef),
+                                                               L.ptr_array8(direct[0]), st),
+                    "seld_hc_conv_bwd_weight_bnpool_acc")
+        dg = db = None
+        if slot is None:
+            dg, db = red[:C], red[C:]
+        elif not clean:
+            axpy_(slot, red, 2 * C)
+        return (None, None, dg, db) + (None,) * (10 + len(ws))
+
+
+def conv_bn_relu_pool(x, ws, bias, bn, ph, pw, stride, padding, dilation):
+    """conv -> BatchNorm2d -> ReLU -> MaxPool2d(ph, pw).  The first stage of the network (x needs no gradient) takes the
+    fused backward above when the shape qualifies; everything else is hyper_conv[_stats] + bn_relu_pool."""
+    k = tuple(ws[0].shape[2:])
+    one = lambda v: v == 1 or tuple(v) == (1, 1) if isinstance(v, (tuple, list)) else v == 1
+    fused = (not x.requires_grad and torch.is_grad_enabled() and x.dim() == 4 and k == (3, 3) and int(pw) == 1 and
+             one(stride) and one(dilation) and x.shape[2] % int(ph) == 0 and x.shape[3] % 32 == 0 and
+             _direct_targets(ws, bias) is not None and not os.environ.get("SELD_NO_FUSED_STAGE0"))
+    if fused:
+        pad = padding if isinstance(padding, (tuple, list)) else (padding, padding)
+        fused = tuple(pad) == (1, 1)          # 'same' 3x3: the output has the input's height and width
+    if fused:
+        return ConvBnReluPoolFn.apply(x, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
+                                      bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(ph), _nbt(bn),
+                                      stride, padding, dilation, *ws)
+    if bn.training:
+        y, stats = hyper_conv_stats(x, ws, bias, stride, padding, dilation)
+    else:
+        y, stats = hyper_conv(x, ws, bias, stride, padding, dilation), None
+    return bn_relu_pool(y, bn, ph, pw, stats)

@@ -247,11 +247,7 @@ class _CnnStage(nn.Sequential):
             bn, pool = mods[1], mods[3]
             s, p, d = _geom(conv)
             ph, pw = hnn._window(pool.kernel_size, 2)
-            if bn.training:
-                y, stats = H.hyper_conv_stats(x, _components(conv), conv.bias, s, p, d)
-            else:
-                y, stats = H.hyper_conv(x, _components(conv), conv.bias, s, p, d), None
-            x = H.bn_relu_pool(y, bn, ph, pw, stats)
+            x = H.conv_bn_relu_pool(x, _components(conv), conv.bias, bn, ph, pw, s, p, d)
             return mods[4](x)
         x = conv(x)
         for m in mods[1:]:

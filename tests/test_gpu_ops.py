@@ -273,3 +273,60 @@ def test_stft_matches_fixture_and_oracle(golden):
     ref = O.spectrum_fast(xl.astype(np.float32).astype(np.float64), 512, 112, output_phase=True)
     assert out.shape == ref.shape
     assert np.abs(out[:3] - ref[:3]).max() < 1e-5
+
+
+@pytest.mark.parametrize("algebra,cin,cout,hw,ph,training", [(8, 8, 192, (16, 64), 8, True), (4, 8, 64, (8, 32), 2, True),
+                                                             (8, 8, 64, (16, 96), 8, False)])
+def test_first_stage_fused_backward(algebra, cin, cout, hw, ph, training, monkeypatch):
+    """conv -> BatchNorm2d -> ReLU -> MaxPool(ph, 1) on an input that needs no gradient: the fused backward
+    (seld_bn_relu_pool_bwd_coef + seld_hc_conv_bwd_weight_bnpool_acc, dy never written) against the unfused path
+    (seld_bn_relu_pool_bwd + seld_hc_conv_bwd_weight_acc), and that one against torch autograd on the CPU in fp64."""
+    P = pkg()
+    H, T = P.hip_ops, P.train
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(3, cin, *hw, generator=gen)
+    ws0 = [torch.randn(cout // algebra, cin // algebra, 3, 3, generator=gen) * 0.3 for _ in range(algebra)]
+    b0 = torch.randn(cout, generator=gen) * 0.1
+    g0, be0 = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.2
+    cot = torch.randn(3, cout, hw[0] // ph, hw[1], generator=gen)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("SELD_NO_FUSED_STAGE0", raising=False)
+        else:
+            monkeypatch.setenv("SELD_NO_FUSED_STAGE0", "1")
+        ws = [torch.nn.Parameter(w.clone().to(DEV)) for w in ws0]
+        bias = torch.nn.Parameter(b0.clone().to(DEV))
+        bn = P.hip_nn.BatchNorm2d(cout).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(g0.to(DEV)); bn.bias.copy_(be0.to(DEV))
+        bn.train(training)
+        opt = T.FlatAdam(ws + [bias] + list(bn.parameters()), lr=1e-3)
+        opt.zero_grad()
+        y = H.conv_bn_relu_pool(x.to(DEV), ws, bias, bn, ph, 1, 1, 1, 1)
+        (y * cot.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().cpu(), [w.grad.detach().cpu().clone() for w in ws], bias.grad.cpu().clone(), \
+            bn.weight.grad.cpu().clone(), bn.bias.grad.cpu().clone(), bn.running_var.cpu().clone()
+
+    got, ref = run(True), run(False)
+    _close(got[0], ref[0], rel=1e-6, what="pooled")
+    for a, b in zip(got[1], ref[1]):
+        _close(a, b, rel=2e-4, what="dw fused vs unfused")
+    _close(got[3], ref[3], rel=1e-5, what="dgamma"); _close(got[4], ref[4], rel=1e-5, what="dbeta")
+    _close(got[5], ref[5], rel=1e-6, what="running_var")
+    # fp64 reference through the oracle's convolution and torch's batch_norm / max_pool2d
+    w64 = [w.double().requires_grad_(True) for w in ws0]
+    b64, g64, be64 = b0.double().requires_grad_(True), g0.double().requires_grad_(True), be0.double().requires_grad_(True)
+    yr = O.hypercomplex_conv(x.double(), w64, b64, 1, 1, 1, 1, mode="explicit")
+    rm, rv = torch.zeros(cout, dtype=torch.float64), torch.ones(cout, dtype=torch.float64)
+    z = F.batch_norm(yr, rm, rv, g64, be64, training=training, momentum=0.1, eps=1e-5)
+    pr = F.max_pool2d(F.relu(z), (ph, 1))
+    (pr * cot.double()).sum().backward()
+    _close(got[0], pr, rel=2e-5, what="pooled vs fp64")
+    for a, b in zip(got[1], w64):
+        _close(a, b.grad, rel=5e-4, what="dw vs fp64")
+    _close(got[3], g64.grad, rel=5e-4, what="dgamma vs fp64")
+    _close(got[4], be64.grad, rel=5e-4, what="dbeta vs fp64")
+    scale = max(float(w64[0].grad.abs().max()), 1e-6)
+    assert float((got[2].double() - b64.grad).abs().max()) < 1e-3 * scale * cot.numel() ** 0.5     # ~0 under batch statistics
