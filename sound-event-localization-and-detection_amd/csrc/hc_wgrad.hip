@@ -600,7 +600,8 @@ int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
     p.KH = d->k[0]; p.KW = d->k[1]; p.sw = d->stride[1]; p.outW = o[1]; p.split_len = 32;
     p.Cout = d->Cout; p.Cin = d->Cin; p.outS = o[0] * o[1]; p.inS = d->in[0] * d->in[1];
     const bool row = hc_wgrad_row_ok(p);
-    snprintf(buf, buflen, "%s<%s, %d, %d>", row ? "hc_wgrad_row_kernel" : (fast ? "hc_wgrad32_kernel" : "hc_wgrad_kernel"), t, kh, kw);
+    if (row) snprintf(buf, buflen, "hc_wgrad_row_kernel<%s, %d, %d, 0>", t, kh, kw);     // last argument: fused BN/pool backward
+    else snprintf(buf, buflen, "%s<%s, %d, %d>", fast ? "hc_wgrad32_kernel" : "hc_wgrad_kernel", t, kh, kw);
     return SELD_OK;
 }
 

@@ -62,15 +62,18 @@ _label_cache = {}
 
 
 class _Timed:
-    def __init__(self, desc, which, mult=1):
+    def __init__(self, desc, which, mult=1, variant=False):
+        """variant: the launch runs the kernel's other instantiation (pair data gradient, fused first-stage weight
+        gradient): its symbol ends in ', 1>' instead of ', 0>'."""
         self.mult = mult
+        self.variant = variant or (mult == 2 and which == 1)
         self.on = kernel_timer.active
         if self.on and kernel_timer.only is not None:
             key = (bytes(desc), which)
             lab = _label_cache.get(key)
             if lab is None:
                 lab = _label_cache[key] = _label(desc, which)
-            if mult == 2 and which == 1 and lab.endswith(", 0>"):
+            if self.variant and lab.endswith(", 0>"):
                 lab = lab[:-4] + ", 1>"
             self.on = lab in kernel_timer.only
         if self.on:
@@ -88,8 +91,8 @@ class _Timed:
             self.e1.record()
             fl, by = conv_work(self.desc, self.which)
             lab = _label(self.desc, self.which)
-            if self.mult == 2 and self.which == 1 and lab.endswith(", 0>"):
-                lab = lab[:-4] + ", 1>"        # the pair instantiation of the data-gradient kernel
+            if self.variant and lab.endswith(", 0>"):
+                lab = lab[:-4] + ", 1>"
             kernel_timer.records.append((lab, self.e0, self.e1, fl * self.mult, by * self.mult))
         return False
 
@@ -1031,7 +1034,7 @@ class ConvBnReluPoolFn(torch.autograd.Function):
                                                    L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(training),
                                                    L.ptr(red), L.ptr(coef), L.ptr(direct[1]), st),
                 "seld_bn_relu_pool_bwd_coef")
-        with _Timed(ctx.desc, 2):
+        with _Timed(ctx.desc, 2, 1, True):
             L.check(L.lib().seld_hc_conv_bwd_weight_bnpool_acc(ctypes.byref(ctx.desc), L.ptr(x), L.ptr(y), L.ptr(pooled),
                                                                L.ptr(dpooled), L.ptr(idx), ph, L.ptr(coef),
                                                                L.ptr_array8(direct[0]), st),
