@@ -52,7 +52,10 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     constexpr int XI = (KC + KSTEP - 1) / KSTEP;
     constexpr int WTOT = BC * NG;
     constexpr int WI = (WTOT + 255) / 256;
-    constexpr int RS = (NG % 2) ? NG : NG + 1;     // row pitch of the W image in 16-byte pieces: odd
+    // Row pitch of the W image in 16-byte pieces: the k-pieces of a row are contiguous (conflict-free 16-byte stores of
+    // consecutive pieces); 6 and 9 both leave the ds_read_b128 fragment reads where they are (SQ_LDS_BANK_CONFLICT is
+    // the same for pitches 9 and 10, and for 7 and 6 -- the remaining conflicts are the 4-byte left-over reads).
+    constexpr int RS = NG;
     static_assert(NL == 1 || NL == 2, "KC is 36 or 24");
     static_assert(KC % KK == 0 && KC % KWAVE == 0, "chunk = whole channels");
 
