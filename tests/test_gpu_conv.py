@@ -241,3 +241,44 @@ def test_conv_epilogues():
     acc = addend.clone()
     H.conv_fwd(desc, x, ws, out=acc, epilogue=L.SELD_EPI_ACCUMULATE)
     assert torch.allclose(acc, base + addend, atol=1e-5)
+
+
+# Full-size layers of the benchmark workload (config 3, batch 32): too big for the CPU oracle, so parity rests on
+# size-independent identities that tie the three kernels of a layer to each other and to linearity:
+#   <conv_W(x), dy> = <x, dgrad_W(dy)> = <W, wgrad(x, dy)>      (adjointness; the Hamilton structure cancels out)
+#   conv_W(a*x1 + b*x2) = a*conv_W(x1) + b*conv_W(x2)
+FULL_LAYERS = [
+    ("cnn0", (32, 8, 128, 512), 192, (3, 3), 1, 1),
+    ("cnn1", (32, 192, 16, 512), 192, (3, 3), 1, 1),
+    ("tcn_k3_d8", (32, 192, 512), 384, (3,), 8, 8),
+    ("tcn_k3_d89", (32, 192, 512), 384, (3,), 89, 89),
+    ("tcn_k1", (32, 384, 512), 192, (1,), 0, 1),
+]
+
+
+@pytest.mark.parametrize("name,shape,cout,k,pad,dil", FULL_LAYERS, ids=[c[0] for c in FULL_LAYERS])
+def test_full_size_adjoint_and_linearity(name, shape, cout, k, pad, dil):
+    import seld_amd
+    H = seld_amd.hip_ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(77)
+    A = 8
+    x = torch.randn(shape, device=dev, generator=gen, requires_grad=True)
+    ws = [(torch.randn((cout // A, shape[1] // A) + tuple(k), device=dev, generator=gen) * 0.1).requires_grad_(True)
+          for _ in range(A)]
+    y = H.hyper_conv(x, ws, None, 1, pad, dil)
+    dy = torch.randn(y.shape, device=dev, generator=gen)
+    lhs = (y.detach().double() * dy.double()).sum()
+    (y * dy).sum().backward()
+    mid = (x.detach().double() * x.grad.double()).sum()
+    rhs = sum((w.detach().double() * w.grad.double()).sum() for w in ws)
+    scale = float(y.detach().double().norm() * dy.double().norm())
+    assert abs(float(lhs - mid)) < 2e-5 * scale, (float(lhs), float(mid))
+    assert abs(float(lhs - rhs)) < 2e-5 * scale, (float(lhs), float(rhs))
+    with torch.no_grad():
+        x2 = torch.randn(shape, device=dev, generator=gen)
+        wd = [w.detach() for w in ws]
+        y12 = H.hyper_conv(0.75 * x.detach() - 1.5 * x2, wd, None, 1, pad, dil)
+        y2 = H.hyper_conv(x2, wd, None, 1, pad, dil)
+        err = float((y12 - (0.75 * y.detach() - 1.5 * y2)).abs().max())
+        assert err < 1e-4 * float(y12.abs().max()), err
