@@ -43,6 +43,14 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const LinP p, int rows
     const int r0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int tr = (tid >> 4) * 4, tn = (tid & 15) * 4;
     float acc[4][4] = {};
+    // B-tile fill without per-element index arithmetic: thread -> column nn = tid & 63, k rows kq, kq+4, kq+8, kq+12
+    const int nn = tid & 63, kq = tid >> 6;
+    const int kblk = (p.kind == SELD_LIN_REAL) ? 16 : (TRANS ? p.OA : p.IA);     // K extent of one component block
+    const int nblk = (p.kind == SELD_LIN_REAL) ? Nn : (TRANS ? p.IA : p.OA);
+    const bool blk_fast = (kblk % 16 == 0);
+    const bool nvalid = n0 + nn < Nn;
+    const int nb = nvalid ? (n0 + nn) / nblk : 0;
+    const int nc = nvalid ? (n0 + nn) - nb * nblk : 0;
     for (int k0 = 0; k0 < K; k0 += 16) {
         // A tile: 64 rows x 16 k (row-major source, k contiguous)
         for (int e = tid; e < 64 * 16; e += 256) {
@@ -51,11 +59,34 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const LinP p, int rows
             if (r0 + r < rows && k0 + k < K) v = A[(size_t)(r0 + r) * K + k0 + k];
             As[k][r] = v;
         }
-        for (int e = tid; e < 64 * 16; e += 256) {
-            const int n = e & 63, k = e >> 6;
-            float v = 0.f;
-            if (n0 + n < Nn && k0 + k < K) v = TRANS ? lin_elem(p, n0 + n, k0 + k) : lin_elem(p, k0 + k, n0 + n);
-            Bs[k][n] = v;
+        if (blk_fast) {
+            // the 16-deep K tile lies inside one component block (kblk | 16): component and sign depend only on this
+            // thread's column, the four elements are one strided walk -- no division per element
+            const int ka = k0 / kblk, kc = k0 - ka * kblk;
+            float sign = 1.f;
+            int comp = 0;
+            if (p.kind == SELD_LIN_QUAT) comp = TRANS ? block_comp(4, ka, nb, &sign) : block_comp(4, nb, ka, &sign);
+            else if (p.kind == SELD_LIN_DUALQ) comp = TRANS ? block_comp(8, nb, ka, &sign) : block_comp(8, ka, nb, &sign);
+            const bool live = nvalid && comp >= 0;
+            // M(i, o) = w[comp][c_in * OA + c_out]: TRANS=0: i = K index (c_in = kc + kk), o = this column (c_out = nc)
+            //                                       TRANS=1: o = K index (c_out = kc + kk), i = this column (c_in = nc)
+            const float* wp = live ? (p.kind == SELD_LIN_REAL
+                                          ? p.w.p[0] + (TRANS ? (size_t)(k0 + kq) * p.in_f + (n0 + nn) : (size_t)(n0 + nn) * p.in_f + k0 + kq)
+                                          : p.w.p[comp] + (TRANS ? (size_t)nc * p.OA + kc + kq : (size_t)(kc + kq) * p.OA + nc))
+                                   : nullptr;
+            const size_t wstep = (p.kind == SELD_LIN_REAL) ? (TRANS ? (size_t)4 * p.in_f : 4) : (TRANS ? 4 : (size_t)4 * p.OA);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = kq + 4 * t;
+                Bs[k][nn] = (live && k0 + k < K) ? sign * wp[t * wstep] : 0.f;
+            }
+        } else {
+            for (int e = tid; e < 64 * 16; e += 256) {
+                const int n = e & 63, k = e >> 6;
+                float v = 0.f;
+                if (n0 + n < Nn && k0 + k < K) v = TRANS ? lin_elem(p, n0 + n, k0 + k) : lin_elem(p, k0 + k, n0 + n);
+                Bs[k][n] = v;
+            }
         }
         __syncthreads();
 #pragma unroll
