@@ -101,9 +101,10 @@ int seld_hc_conv_bwd_weight_acc(const seld_conv_desc* d, const float* x, const f
 /* ---- two convolutions of one geometry in one launch ------------------------------------------------------
  * A residual block calls the hypercomplex convolution twice on the same tensor with the same geometry:
  * conv1_filter | conv1_gate (model.py:121-122) and conv2_skip | conv2_residual (model.py:130-132).  The pair entry
- * points run both in one launch (forward: the grid carries both; data gradient: ONE kernel sums both contributions,
- * its reduction runs over dyA then dyB; weight gradient: the grid carries both).  The layers are ~70 us each on an
- * MI355X, so a launch's fixed cost is a third of it.
+ * points run both in one launch where that pays (data gradient: ONE kernel sums both contributions, its reduction
+ * runs over dyA then dyB; weight gradient: the grid carries both; forward: one launch with two reduction passes per
+ * workgroup on the 1x1 layers, two launches of the single kernel otherwise).  The layers are 30-70 us each on an
+ * MI355X, so a launch's fixed cost is up to a third of it.
  * seld_hc_conv_pair_supported(d, which) (which: 0 forward, 1 data gradient, 2 weight gradient) tells whether the
  * pair form runs for this shape; if not, the entry point returns SELD_EUNSUPPORTED and the caller issues the two
  * single calls. */

@@ -668,9 +668,24 @@ extern "C" int seld_hc_conv_pair_fwd(const seld_conv_desc* d, const float* x, co
                                      const float* const wB[8], const float* biasA, const float* biasB, float* yA,
                                      float* yB, int32_t epilogueA, int32_t epilogueB, const float* addendA,
                                      const float* addendB, float* statsA, float* statsB, void* stream) {
-    // Forward: both passes in one workgroup measured no faster than two launches (141 vs 2 x 68 us on the TCN
-    // layers) and cost the single-convolution kernel registers; the entry point stays for symmetry and issues both.
-    int rc = seld_hc_conv_fwd_ex(d, x, wA, biasA, yA, epilogueA, addendA, statsA, stream);
+    int rc = hc_validate(d);
+    if (rc) return rc;
+    int o[2];
+    hc_out_shape(d, o);
+    if (o[0] <= 0 || o[1] <= 0 || !x || !wA || !wB || !yA || !yB) return SELD_EINVAL;
+    if (((epilogueA & SELD_EPI_ADD) && !addendA) || ((epilogueB & SELD_EPI_ADD) && !addendB)) return SELD_EINVAL;
+    if (((epilogueA & SELD_EPI_STATS) && !statsA) || ((epilogueB & SELD_EPI_STATS) && !statsB)) return SELD_EINVAL;
+    // One launch (two K passes per workgroup) on the 1x1 layers, where a launch's fixed cost is a third of its time;
+    // two launches of the single kernel everywhere else (on the 1x3 layers the pair measured 141 us against 2 x 68).
+    ConvP p{};
+    fill_fwd(p, d, wA, o);
+    p.epilogue = epilogueA; p.src = x; p.bias = biasA; p.dst = yA; p.addend = addendA; p.stats = statsA;
+    p.nslots = 2;
+    for (int i = 0; i < 8; ++i) p.w2.p[i] = (i < d->algebra) ? wB[i] : nullptr;
+    p.epilogue2 = epilogueB; p.src2 = x; p.bias2 = biasB; p.dst2 = yB; p.addend2 = addendB; p.stats2 = statsB;
+    const TileCfg c = pick_cfg(p.Cdst, p.Ptot);
+    if (!getenv("SELD_NO_FWD_PAIR") && hc_conv_vec_try(p, MODE_FWD, c.ct, c.pt, (hipStream_t)stream)) return check_launch();
+    rc = seld_hc_conv_fwd_ex(d, x, wA, biasA, yA, epilogueA, addendA, statsA, stream);
     if (rc) return rc;
     return seld_hc_conv_fwd_ex(d, x, wB, biasB, yB, epilogueB, addendB, statsB, stream);
 }

@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
 
     __shared__ __attribute__((aligned(16))) float Xs[2][KC][XROW];
     __shared__ __attribute__((aligned(16))) float Ws[2][BC][RS][4];
-    __shared__ unsigned wdelta_s[16];              // [slot][component] byte offsets from p.wmin
+    __shared__ unsigned wdelta_s[16];
+    // statistics scratch of a forward pair: the staging buffers hold slot 1's first chunk while slot 0 is written out
+    __shared__ float pair_red_s[(PAIRS && MODE == MODE_FWD) ? 4 * CT * 16 * 2 : 1];              // [slot][component] byte offsets from p.wmin
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -75,9 +77,14 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
         const float* wp_ = tid < 8 ? p.w.p[tid] : p.w2.p[tid - 8];
         wdelta_s[tid] = wp_ ? (unsigned)((const char*)wp_ - (const char*)p.wmin) : 0u;
     }
-    // PAIRS (data gradient only): dst = dgrad(src, w) + dgrad(src2, w2) -- the K loop runs over slot 0's source and
-    // weights, then slot 1's.  A separate instantiation: the extra state costs the single-convolution kernels 10 %.
-    static_assert(!PAIRS || MODE == MODE_DGRAD, "pairs are summed data gradients");
+    // PAIRS: two convolutions in one launch -- the K loop runs over slot 0's source and weights, then slot 1's.
+    //   data gradient: dst = dgrad(src, w) + dgrad(src2, w2), one result;
+    //   forward (1x1 layers, same src): slot 0's result is written after the first pass (its stores drain under the
+    //   second pass), slot 1's at the end.  On the 1x1 layers a launch's fixed cost is a third of its time
+    //   (52 us for the pair against 2 x 33); on the 1x3 layers it did not pay (141 against 2 x 68).
+    // A separate instantiation: the extra state costs the single-convolution kernels 10 %.
+    static_assert(!PAIRS || MODE == MODE_DGRAD || (KH_T == 1 && KW_T == 1), "forward pairs: 1x1 layers only");
+    constexpr bool FWD_PAIR = PAIRS && MODE == MODE_FWD;
     const int zslot = 0;
     const int kslots = PAIRS ? 2 : 1;
     int wslot = zslot;                             // weight set the next chunk to load belongs to
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
                 s2 += __shfl_xor(s2, 16, 64);
                 s2 += __shfl_xor(s2, 32, 64);
                 if (fk == 0) {
-                    float* redbuf = &Xs[0][0][0];          // the K loop is over: the staging buffers are free
+                    float* redbuf = FWD_PAIR ? pair_red_s : &Xs[0][0][0];   // the K loop is over: the staging buffers are free
                     redbuf[(wave * BC + j * 16 + fr) * 2 + 0] = s1;
                     redbuf[(wave * BC + j * 16 + fr) * 2 + 1] = s2;
                 }
@@ -457,12 +464,24 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     // (data gradient of a pair: the chunk ranges are simply run again for the second source; load_chunk's state
     // machine switches descriptor and weights by itself.  Written as straight-line repeats, not as a loop over the
     // slots: the nested loop cost the 12-tile kernels 100+ VGPRs.)
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    };
     auto run_all = [&](auto edgec) __attribute__((always_inline)) {
         if (mixed_wg) {
             const int csplit = (half_k - kbeg) / KC;          // first chunk of the upper K half
             if (p.skip_mode == 1) {                           // forward: primal tiles (lower half) see zeros there
                 run_chunks(0, csplit, IC0{}, ICT{}, edgec);
                 run_chunks(csplit, nchunks, ICH{}, ICT{}, edgec);
+                if (FWD_PAIR) {
+                    epilogue(0);
+                    zero_acc();
+                    run_chunks(0, csplit, IC0{}, ICT{}, edgec);
+                    run_chunks(csplit, nchunks, ICH{}, ICT{}, edgec);
+                }
             } else {                                          // dgrad: dual tiles (upper half) see zeros in the lower K half
                 run_chunks(0, csplit, IC0{}, ICH{}, edgec);
                 run_chunks(csplit, nchunks, IC0{}, ICT{}, edgec);
@@ -471,13 +490,18 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
                     run_chunks(csplit, nchunks, IC0{}, ICT{}, edgec);
                 }
             }
+        } else if (FWD_PAIR) {
+            run_chunks(0, nchunks, IC0{}, ICT{}, edgec);
+            epilogue(0);
+            zero_acc();
+            run_chunks(0, nchunks, IC0{}, ICT{}, edgec);
         } else {
             run_chunks(0, kslots * nchunks, IC0{}, ICT{}, edgec);
         }
     };
     if (edge_wg) run_all(ETrue{});
     else run_all(EFalse{});
-    epilogue(0);
+    epilogue(FWD_PAIR ? 1 : 0);
 
 }
 
@@ -485,7 +509,8 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
 int hc_conv_vec_chunk(const ConvP& p, int mode, int ct, int pt) {
     if (getenv("SELD_CONV_NOVEC")) return 0;
     if (!(ct == 12 || ct == 6) || pt != 1) return 0;
-    if (p.nslots > 1 && (p.KH != 1 || mode != MODE_DGRAD)) return 0;   // pairs: summed data gradients of 1-D layers
+    if (p.nslots > 1 && p.KH != 1) return 0;                            // pairs: 1-D layers
+    if (p.nslots > 1 && mode == MODE_FWD && p.KW != 1) return 0;       // forward pairs: 1x1 layers
     if (!(mode == MODE_FWD || p.wt)) return 0;
     if (p.SDh != 1 || p.SDw != 1 || p.SMh != 1 || p.SMw != 1) return 0;
     if (p.dstW % 4 != 0) return 0;
@@ -504,7 +529,7 @@ static void launch_vec(const ConvP& p, hipStream_t st) {
     constexpr int DG = (MODE == MODE_DGRAD) ? 1 : 0;
     if (p.KH == 3) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 3, 3, MODE, 36, 0>), grid, dim3(256), 0, st, p);
     else if (DG && p.nslots > 1 && p.KW == 3) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 3, MODE, 24, DG>), grid, dim3(256), 0, st, p);
-    else if (DG && p.nslots > 1) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 1, MODE, 24, DG>), grid, dim3(256), 0, st, p);
+    else if (p.nslots > 1) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 1, MODE, 24, 1>), grid, dim3(256), 0, st, p);
     else if (p.KW == 3) hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 3, MODE, 24, 0>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((hc_conv_vec_kernel<CT, 1, 1, 1, MODE, 24, 0>), grid, dim3(256), 0, st, p);
 }

@@ -304,7 +304,7 @@ class HyperConvPairFn(torch.autograd.Function):
         yB = torch.empty_like(yA)
         epiA = (L.SELD_EPI_ADD if addA is not None else 0) | (L.SELD_EPI_STATS if statsA is not None else 0)
         epiB = (L.SELD_EPI_ADD if addB is not None else 0) | (L.SELD_EPI_STATS if statsB is not None else 0)
-        with _Timed(desc, 0, 2):
+        with _Timed(desc, 0, 2, all(v == 1 for v in k)):        # 1x1 pairs run the pair instantiation (one launch)
             rc = L.lib().seld_hc_conv_pair_fwd(
                 ctypes.byref(desc), L.ptr(x), L.ptr_array8([_req(w, "w") for w in wsA]),
                 L.ptr_array8([_req(w, "w") for w in wsB]), L.ptr(_req(biasA, "bias")), L.ptr(_req(biasB, "bias")),
