@@ -133,13 +133,26 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int rows_pe
     const int rbeg = blockIdx.z * rows_per_split;
     int rend = rbeg + rows_per_split;
     if (rend > rows) rend = rows;
+    // register-prefetched: the tiles of the next 16 rows are loaded while these are multiplied
+    const int cc = tid & 63, rq = tid >> 6;
+    float rx[4], rd[4];
+    auto fetch = [&](int r0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = rq + 4 * t;
+            rx[t] = (r0 + r < rend && i0 + cc < in_f) ? x[(size_t)(r0 + r) * in_f + i0 + cc] : 0.f;
+            rd[t] = (r0 + r < rend && o0 + cc < out_f) ? dy[(size_t)(r0 + r) * out_f + o0 + cc] : 0.f;
+        }
+    };
+    if (rbeg < rend) fetch(rbeg);
     for (int r0 = rbeg; r0 < rend; r0 += 16) {
-        for (int e = tid; e < 64 * 16; e += 256) {
-            const int c = e & 63, r = e >> 6;
-            Xs[r][c] = (r0 + r < rend && i0 + c < in_f) ? x[(size_t)(r0 + r) * in_f + i0 + c] : 0.f;
-            Ds[r][c] = (r0 + r < rend && o0 + c < out_f) ? dy[(size_t)(r0 + r) * out_f + o0 + c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            Xs[rq + 4 * t][cc] = rx[t];
+            Ds[rq + 4 * t][cc] = rd[t];
         }
         __syncthreads();
+        if (r0 + 16 < rend) fetch(r0 + 16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float a[4], b[4];
