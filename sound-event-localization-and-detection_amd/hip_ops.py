@@ -203,14 +203,63 @@ def _direct_targets(params, bias):
     return None
 
 
+# ---- weight gradients on a second HIP stream -------------------------------------------------------------
+# A layer's weight gradient and its data gradient both start from dy and are independent; the accumulating weight-
+# gradient kernels write only FlatAdam's gradient slots.  Issued on a side stream they overlap the data gradient and
+# the element-wise kernels that follow it on the main stream: a 70 us kernel on this GPU spends ~13 us ramping up and
+# draining, which another queue fills (measured: two independent 1x3 convolutions 142 -> 121 us).  The main stream
+# joins the side stream when the backward pass ends (autograd engine callback) and in FlatAdam.step().
+_side = {"stream": None, "dirty": False}
+
+
+def _side_enabled():
+    return os.environ.get("SELD_WGRAD_SIDE_STREAM", "1") != "0"
+
+
+def join_side_stream():
+    """Make the current stream wait for everything issued on the side stream."""
+    if _side["dirty"]:
+        ev = torch.cuda.Event()
+        ev.record(_side["stream"])
+        torch.cuda.current_stream().wait_event(ev)
+        _side["dirty"] = False
+
+
+def _on_side_stream(fn, *tensors):
+    """Run `fn` (kernel launches only) on the side stream, ordered after everything already on the current stream.
+    `tensors` are read there: the caching allocator must not recycle them before the side stream is done."""
+    if _side["stream"] is None:
+        _side["stream"] = torch.cuda.Stream()
+    st = _side["stream"]
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    st.wait_event(ev)
+    with torch.cuda.stream(st):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(st)
+    if not _side["dirty"]:
+        _side["dirty"] = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+        except RuntimeError:            # not inside a backward pass: join at once
+            join_side_stream()
+
+
 def _conv_backward(ctx, dy, first_w):
     x = ctx.saved_tensors[0]
     ws = ctx.w_params
     dy = _req(dy, "dy")
-    dx = conv_bwd_data(ctx.desc, dy, ws, tuple(x.shape)) if ctx.needs_input_grad[0] else None
     dws, dbias = [None] * len(ws), None
-    if any(ctx.needs_input_grad[first_w:]) or (ctx.has_bias and ctx.needs_input_grad[1]):
-        direct = _direct_targets(ws, ctx.bias_param)
+    need_w = any(ctx.needs_input_grad[first_w:]) or (ctx.has_bias and ctx.needs_input_grad[1])
+    direct = _direct_targets(ws, ctx.bias_param) if need_w else None
+    if direct is not None and _side_enabled() and ctx.needs_input_grad[0]:
+        _on_side_stream(lambda: conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias, into=direct[0],
+                                                bias_into=direct[1]), x, dy)
+        need_w = False
+    dx = conv_bwd_data(ctx.desc, dy, ws, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+    if need_w:
         if direct is not None:
             conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias, into=direct[0], bias_into=direct[1])
         else:
@@ -304,7 +353,9 @@ class HyperConvPairFn(torch.autograd.Function):
         yB = torch.empty_like(yA)
         epiA = (L.SELD_EPI_ADD if addA is not None else 0) | (L.SELD_EPI_STATS if statsA is not None else 0)
         epiB = (L.SELD_EPI_ADD if addB is not None else 0) | (L.SELD_EPI_STATS if statsB is not None else 0)
-        with _Timed(desc, 0, 2, all(v == 1 for v in k)):        # 1x1 pairs run the pair instantiation (one launch)
+        one_launch = all(v == 1 for v in k)          # 1x1 pairs run the pair instantiation of the kernel
+        # (issuing the second of two launches on the side stream was measured: 14.69 vs 14.58 ms per step, not kept)
+        with _Timed(desc, 0, 2, one_launch):
             rc = L.lib().seld_hc_conv_pair_fwd(
                 ctypes.byref(desc), L.ptr(x), L.ptr_array8([_req(w, "w") for w in wsA]),
                 L.ptr_array8([_req(w, "w") for w in wsB]), L.ptr(_req(biasA, "bias")), L.ptr(_req(biasB, "bias")),
@@ -347,11 +398,16 @@ class HyperConvPairFn(torch.autograd.Function):
         if need_w:
             dirA, dirB = _direct_targets(wsA, biasA), _direct_targets(wsB, biasB)
             if dirA is not None and dirB is not None and _pair_ok(desc, 2):
-                with _Timed(desc, 2, 2):
-                    L.check(lib.seld_hc_conv_pair_bwd_weight_acc(ctypes.byref(desc), L.ptr(x), L.ptr(dyA), L.ptr(dyB),
-                                                                 L.ptr_array8(dirA[0]), L.ptr_array8(dirB[0]),
-                                                                 L.ptr(dirA[1]), L.ptr(dirB[1]), L.current_stream()),
-                            "seld_hc_conv_pair_bwd_weight_acc")
+                def pair_wgrad():
+                    with _Timed(desc, 2, 2):
+                        L.check(lib.seld_hc_conv_pair_bwd_weight_acc(ctypes.byref(desc), L.ptr(x), L.ptr(dyA), L.ptr(dyB),
+                                                                     L.ptr_array8(dirA[0]), L.ptr_array8(dirB[0]),
+                                                                     L.ptr(dirA[1]), L.ptr(dirB[1]), L.current_stream()),
+                                "seld_hc_conv_pair_bwd_weight_acc")
+                if _side_enabled():
+                    _on_side_stream(pair_wgrad, x, dyA, dyB)
+                else:
+                    pair_wgrad()
             else:
                 for ws_, b_, dy_, tgt in ((wsA, biasA, dyA, "A"), (wsB, biasB, dyB, "B")):
                     d_ = _direct_targets(ws_, b_)

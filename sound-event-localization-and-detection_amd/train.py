@@ -99,6 +99,7 @@ class FlatAdam:
             off += n
 
     def step(self, grad_scale=1.0):
+        H.join_side_stream()            # weight gradients issued on the side stream (hip_ops._on_side_stream)
         g = self.param_groups[0]
         self.step_count += 1
         H.adam_flat_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"],
