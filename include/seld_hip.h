@@ -84,6 +84,13 @@ size_t seld_hc_conv_bwd_data_workspace(const seld_conv_desc* d);
 int seld_hc_conv_bwd_data_ex(const seld_conv_desc* d, const float* dy, const float* const w[8],
                              float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* seld_hc_conv_bwd_data_ex in two steps: the weight re-layout (Wt[comp][c][o][k] = W[comp][o][c][k], into a workspace of
+ * seld_hc_conv_bwd_data_workspace(d) bytes) can be issued ahead of time -- the host mirror does it on a side stream during
+ * the forward pass -- and the data gradient then starts from the workspace. */
+int seld_hc_conv_transpose_weights(const seld_conv_desc* d, const float* const w[8], void* workspace,
+                                   size_t workspace_bytes, void* stream);
+int seld_hc_conv_bwd_data_wt(const seld_conv_desc* d, const float* dy, const void* wt_workspace, float* dx, void* stream);
+
 /* dw[c] (component gradients, same shapes as w[c]) and dbias (nullable).  The Hamilton fold
  * (sum of the signed blocks that share a component) is done on device with float atomics, so no
  * workspace is needed any more: seld_hc_conv_bwd_weight_workspace returns 0 and `workspace` may be NULL
@@ -110,11 +117,16 @@ int seld_hc_conv_bwd_weight_acc(const seld_conv_desc* d, const float* x, const f
  * single calls. */
 int seld_hc_conv_pair_supported(const seld_conv_desc* d, int32_t which);
 
+
 int seld_hc_conv_pair_fwd(const seld_conv_desc* d, const float* x, const float* const wA[8], const float* const wB[8],
                           const float* biasA /* nullable */, const float* biasB /* nullable */, float* yA, float* yB,
                           int32_t epilogueA, int32_t epilogueB, const float* addendA /* nullable */,
                           const float* addendB /* nullable */, float* statsA /* nullable */,
                           float* statsB /* nullable */, void* stream);
+
+/* The same from two workspaces filled ahead of time by seld_hc_conv_transpose_weights */
+int seld_hc_conv_pair_bwd_data_wt(const seld_conv_desc* d, const float* dyA, const float* dyB, const void* wtA,
+                                  const void* wtB, float* dx, void* stream);
 
 /* dx = dgrad(dyA, wA) + dgrad(dyB, wB); workspace: 2 * seld_hc_conv_bwd_data_workspace(d) bytes, required */
 int seld_hc_conv_pair_bwd_data(const seld_conv_desc* d, const float* dyA, const float* dyB, const float* const wA[8],

@@ -640,6 +640,40 @@ extern "C" int seld_hc_conv_bwd_data_ex(const seld_conv_desc* d, const float* dy
     return run_conv<MODE_DGRAD>(p, (hipStream_t)stream);
 }
 
+// The data gradient in two steps, so that the weight re-layout can be done ahead of time (the host mirror issues it
+// on a side stream during the forward pass): workspace <- Wt[comp][c][o][k] = W[comp][o][c][k], then the data gradient
+// from that workspace.  seld_hc_conv_bwd_data_ex does both.
+extern "C" int seld_hc_conv_transpose_weights(const seld_conv_desc* d, const float* const w[8], void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+    int rc = hc_validate(d);
+    if (rc) return rc;
+    if (!w || !workspace || workspace_bytes < seld_hc_conv_bwd_data_workspace(d)) return SELD_EINVAL;
+    WPtrs src{};
+    for (int i = 0; i < 8; ++i) src.p[i] = (i < d->algebra) ? w[i] : nullptr;
+    const int OA = d->Cout / d->algebra, IA = d->Cin / d->algebra, KK = d->k[0] * d->k[1];
+    const int per = OA * IA * KK;
+    hipLaunchKernelGGL(hc_transpose_w_kernel, dim3((per * d->algebra + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       src, d->algebra, OA, IA, KK, (float*)workspace);
+    return check_launch();
+}
+
+extern "C" int seld_hc_conv_bwd_data_wt(const seld_conv_desc* d, const float* dy, const void* wt_workspace, float* dx,
+                                        void* stream) {
+    int rc = hc_validate(d);
+    if (rc) return rc;
+    int o[2];
+    hc_out_shape(d, o);
+    if (o[0] <= 0 || o[1] <= 0 || !dy || !wt_workspace || !dx) return SELD_EINVAL;
+    if ((long long)d->Cout * o[0] * o[1] >= (1LL << 28)) return SELD_EUNSUPPORTED;
+    ConvP p{};
+    fill_dgrad(p, d, nullptr, o);
+    p.src = dy; p.bias = nullptr; p.dst = dx;
+    const int per = p.OA * p.IA * p.KH * p.KW;
+    for (int i = 0; i < d->algebra; ++i) p.w.p[i] = (const float*)wt_workspace + (size_t)i * per;
+    p.wt = 1;
+    return run_conv<MODE_DGRAD>(p, (hipStream_t)stream);
+}
+
 namespace seld {
 int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen);
 int hc_wgrad_pair_ok(const seld_conv_desc* d);
@@ -688,6 +722,29 @@ extern "C" int seld_hc_conv_pair_fwd(const seld_conv_desc* d, const float* x, co
     rc = seld_hc_conv_fwd_ex(d, x, wA, biasA, yA, epilogueA, addendA, statsA, stream);
     if (rc) return rc;
     return seld_hc_conv_fwd_ex(d, x, wB, biasB, yB, epilogueB, addendB, statsB, stream);
+}
+
+// dx = dgrad(dyA, wA) + dgrad(dyB, wB) from two workspaces filled by seld_hc_conv_transpose_weights
+extern "C" int seld_hc_conv_pair_bwd_data_wt(const seld_conv_desc* d, const float* dyA, const float* dyB,
+                                             const void* wtA, const void* wtB, float* dx, void* stream) {
+    if (!seld_hc_conv_pair_supported(d, 1)) return SELD_EUNSUPPORTED;
+    if (!dyA || !dyB || !wtA || !wtB || !dx) return SELD_EINVAL;
+    int o[2];
+    hc_out_shape(d, o);
+    if ((long long)d->Cout * o[0] * o[1] >= (1LL << 28)) return SELD_EUNSUPPORTED;
+    ConvP p{};
+    fill_dgrad(p, d, nullptr, o);
+    p.src = dyA; p.bias = nullptr; p.dst = dx;
+    p.nslots = 2; p.src2 = dyB;
+    const int per = p.OA * p.IA * p.KH * p.KW;
+    for (int i = 0; i < d->algebra; ++i) {
+        p.w.p[i] = (const float*)wtA + (size_t)i * per;
+        p.w2.p[i] = (const float*)wtB + (size_t)i * per;
+    }
+    p.wt = 1;
+    const TileCfg c = pick_cfg(p.Cdst, p.Ptot);
+    if (!hc_conv_vec_try(p, MODE_DGRAD, c.ct, c.pt, (hipStream_t)stream)) return SELD_EUNSUPPORTED;
+    return check_launch();
 }
 
 // dx = dgrad(dyA, wA) + dgrad(dyB, wB).  workspace: 2 * seld_hc_conv_bwd_data_workspace(d) bytes (required).

@@ -160,11 +160,19 @@ def conv_fwd(desc, x, ws, bias=None, out=None, epilogue=0, addend=None, stats=No
     return y
 
 
-def conv_bwd_data(desc, dy, ws, x_shape):
+def conv_bwd_data(desc, dy, ws, x_shape, ahead=None):
+    """`ahead`: (workspace, event) from _transpose_ahead -- the weights are already re-laid out."""
     dy = _req(dy, "dy")
-    ws = [_req(w, "w") for w in ws]
     dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
     lib = L.lib()
+    if ahead is not None:
+        wt, ev = ahead
+        torch.cuda.current_stream().wait_event(ev)
+        with _Timed(desc, 1):
+            L.check(lib.seld_hc_conv_bwd_data_wt(ctypes.byref(desc), L.ptr(dy), L.ptr(wt), L.ptr(dx), L.current_stream()),
+                    "seld_hc_conv_bwd_data_wt")
+        return dx
+    ws = [_req(w, "w") for w in ws]
     lib.seld_hc_conv_bwd_data_workspace.restype = ctypes.c_size_t
     nbytes = lib.seld_hc_conv_bwd_data_workspace(ctypes.byref(desc))
     wsb = torch.empty((nbytes + 3) // 4, device=dy.device, dtype=torch.float32)
@@ -247,6 +255,32 @@ def _on_side_stream(fn, *tensors):
             join_side_stream()
 
 
+def _transpose_ahead(desc, ws):
+    """The data gradient's weight re-layout (seld_hc_conv_transpose_weights), issued NOW on the side stream -- i.e. during
+    the forward pass, where it overlaps the convolution -- instead of in front of the data-gradient kernel on the critical
+    path of the backward pass (47 launches of ~5 us per step).  Returns (workspace tensor, event) or None."""
+    if not _side_enabled() or not torch.is_grad_enabled():
+        return None
+    lib = L.lib()
+    lib.seld_hc_conv_bwd_data_workspace.restype = ctypes.c_size_t
+    nbytes = lib.seld_hc_conv_bwd_data_workspace(ctypes.byref(desc))
+    wt = torch.empty((nbytes + 3) // 4, device=ws[0].device, dtype=torch.float32)
+    if _side["stream"] is None:
+        _side["stream"] = torch.cuda.Stream()
+    st = _side["stream"]
+    ev0 = torch.cuda.Event()
+    ev0.record(torch.cuda.current_stream())
+    st.wait_event(ev0)                                   # the weights may still be in flight (Adam of the last step)
+    with torch.cuda.stream(st):
+        L.check(lib.seld_hc_conv_transpose_weights(ctypes.byref(desc), L.ptr_array8([_req(w, "w") for w in ws]), L.ptr(wt),
+                                                   ctypes.c_size_t(nbytes), L.current_stream()),
+                "seld_hc_conv_transpose_weights")
+        ev = torch.cuda.Event()
+        ev.record(st)
+    wt.record_stream(st)
+    return wt, ev
+
+
 def _conv_backward(ctx, dy, first_w):
     x = ctx.saved_tensors[0]
     ws = ctx.w_params
@@ -258,7 +292,7 @@ def _conv_backward(ctx, dy, first_w):
         _on_side_stream(lambda: conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias, into=direct[0],
                                                 bias_into=direct[1]), x, dy)
         need_w = False
-    dx = conv_bwd_data(ctx.desc, dy, ws, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+    dx = conv_bwd_data(ctx.desc, dy, ws, tuple(x.shape), getattr(ctx, "wt_ahead", None)) if ctx.needs_input_grad[0] else None
     if need_w:
         if direct is not None:
             conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias, into=direct[0], bias_into=direct[1])
@@ -280,6 +314,7 @@ class HyperConvFn(torch.autograd.Function):
         ctx.desc = desc
         ctx.has_bias = bias is not None
         ctx.w_params, ctx.bias_param = ws, bias
+        ctx.wt_ahead = _transpose_ahead(desc, ws) if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(x)
         return y
 
@@ -310,6 +345,7 @@ class HyperConvAddFn(torch.autograd.Function):
         ctx.desc = desc
         ctx.has_bias = bias is not None
         ctx.w_params, ctx.bias_param = ws, bias
+        ctx.wt_ahead = _transpose_ahead(desc, ws) if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(x)
         return y
 
@@ -368,6 +404,10 @@ class HyperConvPairFn(torch.autograd.Function):
             L.check(rc, "seld_hc_conv_pair_fwd")
         ctx.desc, ctx.algebra = desc, algebra
         ctx.params = (wsA, wsB, biasA, biasB)
+        ctx.wt_ahead = None
+        if ctx.needs_input_grad[0] and _pair_ok(desc, 1):
+            a_, b_ = _transpose_ahead(desc, wsA), _transpose_ahead(desc, wsB)
+            ctx.wt_ahead = (a_, b_) if a_ is not None and b_ is not None else None
         ctx.save_for_backward(x)
         return yA, yB
 
@@ -380,7 +420,16 @@ class HyperConvPairFn(torch.autograd.Function):
         lib = L.lib()
         dx = None
         if ctx.needs_input_grad[0]:
-            if _pair_ok(desc, 1):
+            if _pair_ok(desc, 1) and ctx.wt_ahead is not None:
+                (wtA, evA), (wtB, evB) = ctx.wt_ahead
+                dx = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+                torch.cuda.current_stream().wait_event(evA)
+                torch.cuda.current_stream().wait_event(evB)
+                with _Timed(desc, 1, 2):
+                    L.check(lib.seld_hc_conv_pair_bwd_data_wt(ctypes.byref(desc), L.ptr(dyA), L.ptr(dyB), L.ptr(wtA),
+                                                              L.ptr(wtB), L.ptr(dx), L.current_stream()),
+                            "seld_hc_conv_pair_bwd_data_wt")
+            elif _pair_ok(desc, 1):
                 dx = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
                 lib.seld_hc_conv_bwd_data_workspace.restype = ctypes.c_size_t
                 nbytes = 2 * lib.seld_hc_conv_bwd_data_workspace(ctypes.byref(desc))
@@ -984,6 +1033,7 @@ class HyperConvStatsFn(torch.autograd.Function):
         ctx.desc = desc
         ctx.has_bias = bias is not None
         ctx.w_params, ctx.bias_param = ws, bias
+        ctx.wt_ahead = _transpose_ahead(desc, ws) if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(x)
         ctx.mark_non_differentiable(stats)
         return y, stats
