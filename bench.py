@@ -140,13 +140,22 @@ def main():
     # Warm-up doubles as the per-kernel survey: every conv launch is bracketed by HIP events to find the dominant
     # kernel.  In the timed region only THAT kernel's launches are bracketed (a few per step), so the event records
     # do not perturb the throughput being measured (bracketing all ~140 launches costs ~4 %).
+    # The survey runs with the weight-gradient side stream off: kernels that overlap on two queues stretch each other's
+    # event brackets, and the survey is about which kernel costs most by itself.  The timed region runs the product
+    # configuration (side stream on); its bracketed kernel is a forward one, which nothing overlaps.
     survey = {}
+    side_env = os.environ.get("SELD_WGRAD_SIDE_STREAM")
     if not args.no_kernel_timer and args.warmup > 0:
         H.kernel_timer.reset()
         H.kernel_timer.only = None
         H.kernel_timer.active = True
+        os.environ["SELD_WGRAD_SIDE_STREAM"] = "0"
     for _ in range(args.warmup):
         step()
+    if side_env is None:
+        os.environ.pop("SELD_WGRAD_SIDE_STREAM", None)
+    else:
+        os.environ["SELD_WGRAD_SIDE_STREAM"] = side_env
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
