@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
         if (p.skip_mode == 1 && c0 + BC <= half_c) kend = half_k;      // all channels primal
         if (p.skip_mode == 2 && c0 >= half_c) kbeg = half_k;           // all channels dual
     }
-    // p.pairing carries SELD_VEC_DBG (timing experiments, wrong results): 4 = one chunk only, 8 = no epilogue stores
+    // p.pairing carries SELD_VEC_DBG (timing experiments, wrong results): 4 = one chunk only, 8 = no epilogue stores,
+    // 16 = return after the setup, 32 = return after staging the first chunk.  On the 1x3 TCN layer (74 us): launch +
+    // setup 2.6 us, first load round trip 2.7, first iteration 4.7 (cold), output write-back 4.5, 23 more iterations 2.4 each
     const int nchunks = (p.pairing & 4) ? 1 : (kend - kbeg) / KC;
     const bool mixed_wg = !(p.pairing & 4) && halves_aligned && (CT % 2 == 0) && (c0 + BC / 2 == half_c);
 
@@ -291,6 +293,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     const int fk = lane >> 4;      // k group of this lane
 
     __syncthreads();               // wdelta_s visible
+    if (p.pairing & 16) return;    // SELD_VEC_DBG timing experiment: setup only
     using ETrue = std::integral_constant<bool, true>;
     using EFalse = std::integral_constant<bool, false>;
     if (nchunks > 0) {
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
         store_chunk(0);
     }
     __syncthreads();
+    if (p.pairing & 32) return;    // SELD_VEC_DBG timing experiment: setup + first chunk staged
 
     // One chunk: [component switch, rare] then ONE basic block -- prefetch of the next chunk into registers, the
     // MFMAs of this one, the registers to the other LDS buffer, barrier.  The prefetch after the last chunk reads
