@@ -160,3 +160,30 @@ def test_dropout_statistics_and_reuse():
 
 def test_smoke_entry():
     pkg().selftest.smoke()
+
+
+def test_full_clip_inference_matches_oracle():
+    """SURVEY 8(f) N2 -- the inference shape of `evaluate_test` (train.py:84-104): one whole clip, B = 1, T = 4800 frames
+    at the config-3 widths, eval mode.  The attention then runs at Tq = 2400 (its T x T energy tensor, 184 MB per
+    sample in the reference, is never built) and every T-dependent kernel sees a length it is not tuned for.  The oracle
+    (the reference's algorithm on the CPU) runs the same clip; tolerance as for every other model test."""
+    import time
+    from tests.golden.cases import model_kwargs
+    case = dict(next(c for c in MODEL_CASES if c["name"] == "c3_F128"), time_dim=4800, B=1)
+    m = _prepared(case).eval()
+    x = O.closed_form_input((1, case["input_channels"], case["freq_dim"], case["time_dim"]))
+    with torch.no_grad():
+        m(x.to(DEV))                                   # warm-up (module load)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sed, doa = m(x.to(DEV))
+        torch.cuda.synchronize()
+        gpu_s = time.perf_counter() - t0
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        t0 = time.perf_counter()
+        rsed, rdoa = O.seld_forward(sd, O.SeldConfig(**model_kwargs(case)), x, train=False)
+        cpu_s = time.perf_counter() - t0
+    print(f"full clip (1, 8, 128, 4800): HIP {gpu_s * 1e3:.1f} ms, oracle {cpu_s:.1f} s")
+    assert tuple(sed.shape) == (1, 600, 42) and tuple(doa.shape) == (1, 600, 126)
+    assert np.abs(_np(sed) - _np(rsed)).max() < 1e-3
+    assert np.abs(_np(doa) - _np(rdoa)).max() < 1e-3
