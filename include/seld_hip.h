@@ -324,6 +324,22 @@ int seld_stft_frames(int32_t L, int32_t nperseg, int32_t noverlap);   /* frames 
 int seld_stft_magphase(const float* x, int32_t C, int32_t L, int32_t nperseg, int32_t noverlap,
                        int32_t output_phase, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Dataset normalisation, in place on a resident predictor array x (items, channels, hw) fp32
+ * (SURVEY 8(f) N1).
+ * seld_dq_unit_norm replaces train.py:257-275 (and its copies for the validation / test arrays,
+ *   277-308): channels 0..7 of every position are one dual quaternion (q, p); p <- p - (q.p/|q|^2) q,
+ *   q <- q/|q|.  channels >= 8; further channels are left untouched.  Same operation order as the
+ *   reference's torch expressions (a zero q yields NaN there and here).
+ * seld_group_standardize replaces train.py:341-349 (and 350-405 for the other arrays / groups):
+ *   g = x[:, c0:c1]; g <- (g - mean(g)) / std(g) with one scalar mean and one population std over the
+ *   whole group.  work: 2 doubles of device scratch (cleared by the call); mean_std: 2 device floats
+ *   receiving the float32 mean and std that were applied, or NULL.  An empty group is SELD_EINVAL.
+ * ------------------------------------------------------------------------------------------ */
+int seld_dq_unit_norm(float* x, int64_t items, int32_t channels, int64_t hw, void* stream);
+int seld_group_standardize(float* x, int64_t items, int32_t channels, int32_t c0, int32_t c1, int64_t hw,
+                           double* work, float* mean_std, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

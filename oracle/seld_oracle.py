@@ -514,6 +514,52 @@ def spectrum_fast(x: np.ndarray, nperseg=512, noverlap=128, cut_dc=True, output_
 
 
 # --------------------------------------------------------------------------------------
+# Dataset normalisation  (train.py:242-408)
+# --------------------------------------------------------------------------------------
+def dq_unit_norm(x: torch.Tensor) -> torch.Tensor:
+    """train.py:257-275: channels 0..7 = (q, p) -> (q/|q|, p - (q.p/|q|^2) q), in the array's own dtype, the
+    reference's operation order.  Returns a new tensor; further channels are copied."""
+    x = x.clone()
+    q = [x[:, i:i + 1] for i in range(4)]
+    p = [x[:, i:i + 1] for i in range(4, 8)]
+    den0 = q[0] ** 2 + q[1] ** 2 + q[2] ** 2 + q[3] ** 2
+    den1 = torch.sqrt(den0)
+    cross = q[0] * p[0] + q[1] * p[1] + q[2] * p[2] + q[3] * p[3]
+    pn = [p[i] - cross / den0 * q[i] for i in range(4)]
+    qn = [q[i] / den1 for i in range(4)]
+    x[:, :8] = torch.cat(qn + pn, dim=1)
+    return x
+
+
+def group_standardize(x: np.ndarray, c0: int, c1: int) -> np.ndarray:
+    """train.py:345-349: x[:, c0:c1] -= mean; /= std (numpy, the array's own dtype, population std)."""
+    x = np.array(x)
+    m = np.mean(x[:, c0:c1, :, :])
+    s = np.std(x[:, c0:c1, :, :])
+    x[:, c0:c1, :, :] -= m
+    x[:, c0:c1, :, :] /= s
+    return x
+
+
+def normalize_dataset(x: np.ndarray, dataset_normalization: str, n_mics: int, domain: str, phase: bool) -> np.ndarray:
+    """The branch structure of train.py:242-408 for ONE predictor array (the reference repeats it for the
+    training / validation / test arrays); returns float32 as train.py:425 does."""
+    mode = str(dataset_normalization)
+    if mode not in {'False', 'false', 'None', 'none'}:
+        if mode in {'DQ_Normalization', 'UnitNormNormalization', 'UnitNorm'}:
+            if n_mics == 2 and domain in ['DQ', 'dq', 'dQ', 'Dual_Quaternion', 'dual_quaternion']:
+                if phase:
+                    raise ValueError('DATASET NORMALIZATION FOR PHASE DUAL QUATERNION NOT YET IMPLEMENTED')
+                x = dq_unit_norm(torch.tensor(x)).numpy()
+        elif n_mics in (1, 2):
+            mag = 4 * n_mics
+            x = group_standardize(x, 0, mag)
+            if phase:
+                x = group_standardize(x, mag, x.shape[1])
+    return torch.tensor(np.array(x)).float().numpy()
+
+
+# --------------------------------------------------------------------------------------
 # Deterministic fills shared by the fixture generator, the tests and the HIP model
 # --------------------------------------------------------------------------------------
 def closed_form_fill_(named_tensors, amp=0.3):

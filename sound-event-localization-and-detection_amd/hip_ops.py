@@ -1000,6 +1000,41 @@ def stft_magphase(x, nperseg=512, noverlap=128, output_phase=True):
     return out
 
 
+
+def _req_inplace(x, name, min_channels=1):
+    if not x.is_cuda:
+        raise L.SeldHipError(f"{name}: expected a HIP device tensor (this package has no CPU path)")
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() < 2:
+        raise L.SeldHipError(f"{name}: expected a contiguous float32 (items, channels, ...) tensor, got {x.dtype} "
+                             f"{tuple(x.shape)} contiguous={x.is_contiguous()}")
+    if x.shape[1] < min_channels:
+        raise L.SeldHipError(f"{name}: needs at least {min_channels} channels, got {x.shape[1]}")
+    items, channels = x.shape[0], x.shape[1]
+    hw = x.numel() // max(1, items * channels)
+    return items, channels, hw
+
+
+def dq_unit_norm_(x):
+    """In place: channels 0..7 of every (item, f, t) position become a unit dual quaternion
+    (train.py:257-275).  x: (items, >=8, F, T) float32 on the device."""
+    items, channels, hw = _req_inplace(x, "dq_unit_norm_", 8)
+    L.check(L.lib().seld_dq_unit_norm(L.ptr(x), ctypes.c_int64(items), channels, ctypes.c_int64(hw), L.current_stream()),
+            "seld_dq_unit_norm")
+    return x
+
+
+def group_standardize_(x, c0, c1):
+    """In place: x[:, c0:c1] <- (x[:, c0:c1] - mean) / std with one scalar mean / population std over the
+    whole group (train.py:345-349).  Returns a 2-element device tensor (mean, std) as applied."""
+    items, channels, hw = _req_inplace(x, "group_standardize_")
+    c0, c1 = int(c0), min(int(c1), channels)        # a numpy slice clips at the channel count
+    work = torch.empty(2, device=x.device, dtype=torch.float64)
+    mean_std = torch.empty(2, device=x.device, dtype=torch.float32)
+    L.check(L.lib().seld_group_standardize(L.ptr(x), ctypes.c_int64(items), channels, c0, c1, ctypes.c_int64(hw), L.ptr(work),
+                                           L.ptr(mean_std), L.current_stream()), "seld_group_standardize")
+    return mean_std
+
+
 _identity_cache = {}
 
 

@@ -270,6 +270,49 @@ def load_pickled(pred_path, target_path):
     return torch.tensor(x).float(), torch.tensor(y).float()
 
 
+_NORM_OFF = {'False', 'false', 'None', 'none'}
+_NORM_UNIT = {'DQ_Normalization', 'UnitNormNormalization', 'UnitNorm'}
+_DOMAIN_DQ = ['DQ', 'dq', 'dQ', 'Dual_Quaternion', 'dual_quaternion']
+
+
+def normalize_dataset(args, *predictors):
+    """Dataset normalisation of train.py:242-408, in place on device-resident predictor arrays
+    (items, channels, F, T) - the reference's training / validation / test predictors, each normalised with its
+    OWN statistics as the reference does.  Returns the description the reference appends to `dataset_string`.
+
+      off ('False' / 'None')                        -> untouched
+      'UnitNorm' family, 2 mics, DQ domain          -> unit dual quaternion per position (train.py:257-308);
+                                                       with --phase the reference raises ValueError (train.py:310)
+      'UnitNorm' family otherwise                   -> untouched (the reference has no branch for it)
+      anything else ('True')                        -> (g - mean) / std over the magnitude channels
+                                                       (first 4 for 1 mic, first 8 for 2 mics) and, with --phase,
+                                                       separately over the remaining channels (train.py:341-405)
+    """
+    mode = str(args.dataset_normalization)
+    if mode in _NORM_OFF:
+        return ''
+    if mode in _NORM_UNIT:
+        if args.n_mics == 2 and args.domain in _DOMAIN_DQ:
+            if args.phase:
+                raise ValueError('DATASET NORMALIZATION FOR PHASE DUAL QUATERNION NOT YET IMPLEMENTED')
+            for x in predictors:
+                H.dq_unit_norm_(x)
+            return ' Dataset Normalization for 2Mic 8Ch Magnitude Dual Quaternion UnitNorm'
+        return ''
+    if args.n_mics not in (1, 2):
+        return ''
+    mag = 4 * args.n_mics
+    for x in predictors:
+        H.group_standardize_(x, 0, mag)
+        if args.phase:
+            H.group_standardize_(x, mag, x.shape[1])
+    what = f'{args.n_mics}Mic {mag}Ch Magnitude'
+    desc = ' Dataset Normalization for ' + what
+    if args.phase:
+        desc += f' Dataset Normalization for {args.n_mics}Mic {2 * mag}Ch Magnitude-Phase'
+    return desc
+
+
 def evaluate(model, device, criterion_sed, criterion_doa, loader, args):
     """Mean loss over a loader, no grad (train.py:168-183)."""
     model.eval()
@@ -303,10 +346,12 @@ def main(args):
     else:
         xs, ys = load_pickled(args.training_predictors_path, args.training_target_path)
         xv, yv = load_pickled(args.validation_predictors_path, args.validation_target_path)
+        xs, xv = xs.to(device), xv.to(device)           # 288 GB of HBM: the arrays stay resident, loaders index them
+        print(normalize_dataset(args, xs, xv))
         tr_data = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xs, ys), args.batch_size, shuffle=True,
-                                              pin_memory=True)
+                                              pin_memory=False)
         val_data = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xv, yv), args.batch_size, shuffle=False,
-                                               pin_memory=True)
+                                               pin_memory=False)
 
     model_dir = os.path.join(args.checkpoint_dir, model.model_name)
     os.makedirs(model_dir, exist_ok=True)

@@ -3,6 +3,7 @@ and by the tests (run against the oracle and the HIP path).  Pure data + closed-
 nothing here touches /root/reference."""
 import math
 
+import numpy as np
 import torch
 
 from oracle.seld_oracle import closed_form_input
@@ -124,3 +125,28 @@ def train_target(case, dtype=torch.float32):
     n = torch.arange(B * t_out * n_sed * 3, dtype=torch.float64)
     doa = (0.9 * torch.sin(0.013 * n)).view(B, t_out, n_sed * 3)
     return torch.cat((sed, doa), dim=2).to(dtype)
+
+
+# dataset normalisation: fixtures in norm.npz hold the three arrays the reference hands to its
+# TensorDatasets (train.py:425-433) for these inputs
+NORM_CASES = [
+    # name, shape, dtype, dataset_normalization, n_mics, domain, phase
+    ("unit_f32", (5, 8, 6, 10), np.float32, "UnitNorm", 2, "DQ", False),
+    ("unit_f32_odd", (3, 10, 5, 7), np.float32, "DQ_Normalization", 2, "dq", False),
+    ("unit_f64", (5, 8, 6, 10), np.float64, "UnitNorm", 2, "DQ", False),
+    ("unit_not_dq", (2, 8, 4, 4), np.float32, "UnitNorm", 2, "Q", False),
+    ("std_2mic_phase", (4, 16, 8, 12), np.float32, "True", 2, "DQ", True),
+    ("std_2mic_phase_odd", (3, 16, 5, 7), np.float32, "True", 2, "DQ", True),
+    ("std_2mic", (4, 8, 8, 12), np.float32, "True", 2, "DQ", False),
+    ("std_1mic_phase", (6, 8, 4, 9), np.float32, "True", 1, "Q", True),
+    ("std_1mic", (6, 4, 4, 8), np.float32, "True", 1, "Q", False),
+    ("std_2mic_phase_f64", (4, 16, 8, 12), np.float64, "True", 2, "DQ", True),
+    ("off", (2, 8, 4, 4), np.float32, "False", 2, "DQ", False),
+]
+
+
+def norm_input(shape, dtype, salt):
+    """Closed form, regenerated by the tests: spectrogram-like positive magnitudes with a spread of scales."""
+    n = np.arange(int(np.prod(shape)), dtype=np.float64)
+    v = 0.7 + np.sin(0.37 * n + salt) * 0.5 + 0.3 * np.cos(0.0113 * n * (salt + 1)) + 0.002 * (n % 97)
+    return v.reshape(shape).astype(dtype)

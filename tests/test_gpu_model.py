@@ -159,7 +159,8 @@ def test_dropout_statistics_and_reuse():
 
 
 def test_smoke_entry():
-    pkg().selftest.smoke()
+    import __graft_entry__
+    __graft_entry__.smoke()
 
 
 def test_full_clip_inference_matches_oracle():

@@ -173,3 +173,18 @@ def test_stft_matches_reference(golden):
     c = O.spectrum_fast(x, 512, 128, output_phase=True)
     assert c.shape == g["magphase_128"].shape
     assert np.abs(c[:nb] - g["magphase_128"][:nb]).max() < 1e-12
+
+
+def test_dataset_normalisation_matches_reference(golden):
+    """norm.npz = the arrays the reference's train.main hands to its TensorDatasets (make_golden.gen_norm);
+    the oracle restatement must reproduce them bit for bit (same torch / numpy primitives, same dtype)."""
+    from tests.golden.cases import NORM_CASES, norm_input
+    g = golden("norm")
+    for name, shape, dtype, mode, n_mics, domain, phase in NORM_CASES:
+        for k in range(3):
+            got = O.normalize_dataset(norm_input(shape, dtype, k), mode, n_mics, domain, phase)
+            ref = g[f"{name}.{k}"]
+            assert got.dtype == np.float32 and got.shape == ref.shape
+            assert np.array_equal(got, ref), (name, k, np.abs(got - ref).max())
+    with pytest.raises(ValueError):
+        O.normalize_dataset(norm_input((2, 16, 4, 4), np.float32, 0), "UnitNorm", 2, "DQ", True)
