@@ -330,10 +330,10 @@ int seld_stft_magphase(const float* x, int32_t C, int32_t L, int32_t nperseg, in
  * seld_dq_unit_norm replaces train.py:257-275 (and its copies for the validation / test arrays,
  *   277-308): channels 0..7 of every position are one dual quaternion (q, p); p <- p - (q.p/|q|^2) q,
  *   q <- q/|q|.  channels >= 8; further channels are left untouched.  Same operation order as the
- *   reference's torch expressions (a zero q yields NaN there and here).
+ *   reference's torch expressions, every operation correctly rounded (a zero q yields NaN there and here).
  * seld_group_standardize replaces train.py:341-349 (and 350-405 for the other arrays / groups):
  *   g = x[:, c0:c1]; g <- (g - mean(g)) / std(g) with one scalar mean and one population std over the
- *   whole group.  work: 2 doubles of device scratch (cleared by the call); mean_std: 2 device floats
+ *   whole group.  work: 3 doubles of device scratch (cleared by the call); mean_std: 2 device floats
  *   receiving the float32 mean and std that were applied, or NULL.  An empty group is SELD_EINVAL.
  * ------------------------------------------------------------------------------------------ */
 int seld_dq_unit_norm(float* x, int64_t items, int32_t channels, int64_t hw, void* stream);

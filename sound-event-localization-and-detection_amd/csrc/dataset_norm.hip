@@ -9,12 +9,13 @@
 //     one scalar mean and one population std over the whole group.
 //
 // Both are HBM-bound streaming passes: 64 B per position for the unit norm (8 planes read + written),
-// 4 + 4 + 8 B per element for the standardisation (sum pass, centred square pass, apply pass).  Every access
+// 4 + 8 B per element for the standardisation (one moments pass, one apply pass).  Every access
 // is a 16-byte load/store along the contiguous (f, t) axis; one item's group is one contiguous segment.
 //
 // The unit norm evaluates the reference's expression tree operation by operation (no FMA contraction,
-// IEEE divide and square root), so its results equal torch's CPU results bit for bit, NaN for a zero q
-// included.  The moments are accumulated in double (numpy: float32 pairwise sums) and rounded to float32
+// correctly rounded divide and square root): bit for bit the IEEE 754 value of that tree, NaN for a zero q
+// included.  (torch's CPU sqrt is 1 ulp off for ~0.6 % of inputs, so the reference's own q channels are
+// reproduced to 1 ulp, its p channels exactly.)  The moments are accumulated in double (numpy: float32 pairwise sums) and rounded to float32
 // once, then applied with the reference's two float32 operations (subtract, divide).
 #include "common.h"
 
@@ -100,17 +101,17 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// PASS 0: acc[0] += sum(x)   PASS 1: acc[1] += sum((x - mean)^2) with mean = float32(acc[0] / count)
-// (numpy's std subtracts the float32 mean in float32: _methods.py _var)
-template <int V, int PASS>
+// One read of the group gives both moments: acc[0] += sum(x - K), acc[1] += sum((x - K)^2) in double, K = the group's
+// first element (a pilot shift, so the variance below does not cancel when |mean| >> std).
+template <int V>
 __global__ __launch_bounds__(256) void group_moment_kernel(const float* __restrict__ x, long long items, long long item_stride,
-                                                           long long seg, double count, double* __restrict__ acc) {
+                                                           long long seg, double* __restrict__ acc) {
     typedef typename Vec<V>::T VT;
-    __shared__ double part[4];
+    __shared__ double part[2][4];
     const long long nv = seg / V;
-    float mean = 0.f;
-    if (PASS == 1) mean = (float)(acc[0] / count);
-    double s = 0.0;
+    const double pilot = (double)x[0];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) acc[2] = pilot;     // x[0] is overwritten by the apply pass
+    double s1 = 0.0, s2 = 0.0;
     for (long long n = blockIdx.y; n < items; n += gridDim.y) {
         const VT* base = reinterpret_cast<const VT*>(x + n * item_stride);
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
@@ -118,30 +119,35 @@ __global__ __launch_bounds__(256) void group_moment_kernel(const float* __restri
             const float* f = reinterpret_cast<const float*>(&v);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                if (PASS == 0) {
-                    s += (double)f[e];
-                } else {
-                    const float d = f[e] - mean;
-                    s += (double)d * (double)d;
-                }
+                const double d = (double)f[e] - pilot;
+                s1 += d;
+                s2 = fma(d, d, s2);
             }
         }
     }
-    s = wave_sum_f64(s);
+    s1 = wave_sum_f64(s1);
+    s2 = wave_sum_f64(s2);
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) part[wave] = s;
+    if ((threadIdx.x & 63) == 0) {
+        part[0][wave] = s1;
+        part[1][wave] = s2;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc + PASS, (part[0] + part[1]) + (part[2] + part[3]));
+    if (threadIdx.x < 2) atomicAdd(acc + threadIdx.x, (part[threadIdx.x][0] + part[threadIdx.x][1]) +
+                                                         (part[threadIdx.x][2] + part[threadIdx.x][3]));
 }
 
+// mean = K + S1/n, var = S2/n - (S1/n)^2, both rounded to float32 once (numpy returns float32 scalars), then the
+// reference's two float32 operations: subtract, divide
 template <int V>
 __global__ __launch_bounds__(256) void group_apply_kernel(float* __restrict__ x, long long items, long long item_stride, long long seg,
                                                           double count, const double* __restrict__ acc,
                                                           float* __restrict__ mean_std) {
     typedef typename Vec<V>::T VT;
     const long long nv = seg / V;
-    const float mean = (float)(acc[0] / count);
-    const float sd = (float)sqrt(acc[1] / count);
+    const double m1 = acc[0] / count;
+    const float mean = (float)(acc[2] + m1);
+    const float sd = (float)sqrt(fmax(acc[1] / count - m1 * m1, 0.0));
     if (mean_std && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         mean_std[0] = mean;
         mean_std[1] = sd;
@@ -197,20 +203,18 @@ extern "C" int seld_group_standardize(float* x, int64_t items, int32_t channels,
     if (!x || !work || items < 0 || channels <= 0 || c0 < 0 || c1 > channels || c0 > c1 || hw < 0) return SELD_EINVAL;
     if (items == 0 || hw == 0 || c0 == c1) return SELD_EINVAL;      // numpy: mean of an empty slice is nan + a warning
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(work, 0, 2 * sizeof(double), st) != hipSuccess) return SELD_ELAUNCH;
+    if (hipMemsetAsync(work, 0, 3 * sizeof(double), st) != hipSuccess) return SELD_ELAUNCH;
     const long long stride = (long long)channels * hw;
     const long long seg = (long long)(c1 - c0) * hw;
     const double count = (double)items * (double)seg;
     float* g = x + (long long)c0 * hw;
     if (vec4_ok(g, hw, stride)) {
         dim3 grid = stream_grid(seg / 4, items, 4);
-        hipLaunchKernelGGL((group_moment_kernel<4, 0>), grid, dim3(256), 0, st, g, (long long)items, stride, seg, count, work);
-        hipLaunchKernelGGL((group_moment_kernel<4, 1>), grid, dim3(256), 0, st, g, (long long)items, stride, seg, count, work);
+        hipLaunchKernelGGL(group_moment_kernel<4>, grid, dim3(256), 0, st, g, (long long)items, stride, seg, work);
         hipLaunchKernelGGL(group_apply_kernel<4>, grid, dim3(256), 0, st, g, (long long)items, stride, seg, count, work, mean_std);
     } else {
         dim3 grid = stream_grid(seg, items, 4);
-        hipLaunchKernelGGL((group_moment_kernel<1, 0>), grid, dim3(256), 0, st, g, (long long)items, stride, seg, count, work);
-        hipLaunchKernelGGL((group_moment_kernel<1, 1>), grid, dim3(256), 0, st, g, (long long)items, stride, seg, count, work);
+        hipLaunchKernelGGL(group_moment_kernel<1>, grid, dim3(256), 0, st, g, (long long)items, stride, seg, work);
         hipLaunchKernelGGL(group_apply_kernel<1>, grid, dim3(256), 0, st, g, (long long)items, stride, seg, count, work, mean_std);
     }
     return check_launch();

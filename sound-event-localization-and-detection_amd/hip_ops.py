@@ -1028,7 +1028,7 @@ def group_standardize_(x, c0, c1):
     whole group (train.py:345-349).  Returns a 2-element device tensor (mean, std) as applied."""
     items, channels, hw = _req_inplace(x, "group_standardize_")
     c0, c1 = int(c0), min(int(c1), channels)        # a numpy slice clips at the channel count
-    work = torch.empty(2, device=x.device, dtype=torch.float64)
+    work = torch.empty(3, device=x.device, dtype=torch.float64)
     mean_std = torch.empty(2, device=x.device, dtype=torch.float32)
     L.check(L.lib().seld_group_standardize(L.ptr(x), ctypes.c_int64(items), channels, c0, c1, ctypes.c_int64(hw), L.ptr(work),
                                            L.ptr(mean_std), L.current_stream()), "seld_group_standardize")

@@ -188,3 +188,8 @@ def test_dataset_normalisation_matches_reference(golden):
             assert np.array_equal(got, ref), (name, k, np.abs(got - ref).max())
     with pytest.raises(ValueError):
         O.normalize_dataset(norm_input((2, 16, 4, 4), np.float32, 0), "UnitNorm", 2, "DQ", True)
+    # the IEEE evaluation the HIP kernel is held to: p channels identical to the reference, q within 1 ulp
+    x = norm_input((5, 8, 6, 10), np.float32, 0)
+    ieee, ref = O.dq_unit_norm_ieee(x), g["unit_f32.0"]
+    assert np.array_equal(ieee[:, 4:], ref[:, 4:])
+    assert np.abs(ieee[:, :4] - ref[:, :4]).max() <= np.spacing(np.float32(1.0))
