@@ -184,8 +184,9 @@ static bool vec4_ok(const void* x, long long a, long long b) {
 using namespace seld;
 
 extern "C" int seld_dq_unit_norm(float* x, int64_t items, int32_t channels, int64_t hw, void* stream) {
-    if (!x || items < 0 || channels < 8 || hw < 0) return SELD_EINVAL;
-    if (items == 0 || hw == 0) return SELD_OK;
+    if (items < 0 || channels < 8 || hw < 0) return SELD_EINVAL;
+    if (items == 0 || hw == 0) return SELD_OK;          // an empty array has no storage: x may be NULL
+    if (!x) return SELD_EINVAL;
     const long long stride = (long long)channels * hw;
     hipStream_t st = (hipStream_t)stream;
     if (vec4_ok(x, hw, hw)) {

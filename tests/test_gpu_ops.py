@@ -362,7 +362,7 @@ def test_dataset_normalisation_matches_reference_fixture(golden):
                 ieee = O.dq_unit_norm_ieee(norm_input(shape, dtype, k)) if unit else ref
                 assert np.array_equal(got, ieee), (name, k, np.abs(got - ieee).max())
                 assert np.array_equal(got[:, 4:], ref[:, 4:])
-                assert np.abs(got[:, :4] - ref[:, :4]).max() <= np.spacing(np.float32(1.0))
+                assert np.abs(got[:, :4] - ref[:, :4]).max() <= 2 * np.spacing(np.float32(1.0))
             else:
                 _close(got, ref, rel=1e-5, what=f"{name}.{k}")
     with pytest.raises(ValueError):
@@ -382,7 +382,7 @@ def test_dq_unit_norm_edge_cases():
     got = H.dq_unit_norm_(x.to(DEV)).cpu()
     assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.isnan(ref).any()
     assert np.array_equal(got.numpy(), ieee, equal_nan=True)
-    assert np.nanmax(np.abs(got.numpy() - ref.numpy()) / np.maximum(np.abs(ref.numpy()), 1e-30)) <= 1.2e-7
+    assert np.nanmax(np.abs(got.numpy() - ref.numpy()) / np.maximum(np.abs(ref.numpy()), 1e-30)) <= 2.4e-7   # 1 ulp of sqrt -> up to 2 ulp of q
     H.dq_unit_norm_(torch.zeros(0, 8, 4, 4, device=DEV))
     with pytest.raises(L.SeldHipError):
         H.dq_unit_norm_(torch.zeros(2, 4, 4, 4, device=DEV))
@@ -423,7 +423,7 @@ def test_dataset_normalisation_full_size_properties():
     ref = O.dq_unit_norm(host)
     t_unit = time.perf_counter() - t0
     assert np.array_equal(O.dq_unit_norm_ieee(host.numpy()), y[:4].cpu().numpy())     # bit-exact at full clip size too
-    assert float((ref - y[:4].cpu()).abs().max()) <= 1.2e-7
+    assert float((ref - y[:4].cpu()).abs().max()) <= 2.4e-7
     t0 = time.perf_counter()
     O.group_standardize(host.numpy(), 0, 8)
     t_std = time.perf_counter() - t0
