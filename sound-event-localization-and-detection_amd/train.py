@@ -106,14 +106,72 @@ class FlatAdam:
                          g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], grad_scale)
 
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,
-                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+        """torch.optim.Adam's layout (the reference saves `optimizer.state_dict()`, train.py:36): per-parameter
+        `step / exp_avg / exp_avg_sq` keyed by the parameter's index in `model.parameters()` order plus one
+        param group with torch's hyper-parameter keys, so the reference's `load_model` accepts our checkpoints.
+        Every parameter gets an entry once a step was taken (torch omits parameters that never had a gradient;
+        an extra entry is ignored by torch for as long as the parameter has no gradient)."""
+        state = {}
+        if self.step_count > 0:
+            off = 0
+            for i, p in enumerate(self.params):
+                n = p.numel()
+                state[i] = dict(step=torch.tensor(float(self.step_count)),
+                                exp_avg=self.exp_avg[off:off + n].view(p.shape).clone(),
+                                exp_avg_sq=self.exp_avg_sq[off:off + n].view(p.shape).clone())
+                off += n
+        group = dict(_torch_adam_defaults())
+        group.update({k: v for k, v in self.param_groups[0].items() if k != "params"})
+        group["params"] = list(range(len(self.params)))
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups[0].update(sd["param_groups"][0])
+        """Accepts torch.optim.Adam's layout (reference checkpoints) and this class's round-1 flat layout."""
+        if "exp_avg" in sd:                                   # flat layout
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.param_groups[0].update(sd["param_groups"][0])
+            return
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        index_of = {pid: i for i, pid in enumerate(groups[0]["params"])}
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        offsets, off = [], 0
+        for p in self.params:
+            offsets.append(off)
+            off += p.numel()
+        steps = set()
+        for pid, st in sd["state"].items():
+            i = index_of[pid]
+            p, o = self.params[i], offsets[i]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state of parameter {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+            self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a checkpoint of one Adam over the model")
+        self.step_count = steps.pop() if steps else 0
+        for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+            if k in groups[0]:
+                self.param_groups[0][k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
+        if groups[0].get("amsgrad") or groups[0].get("maximize"):
+            raise ValueError("amsgrad / maximize checkpoints are not supported (the reference never sets them)")
+
+
+_ADAM_DEFAULTS = None
+
+
+def _torch_adam_defaults():
+    """Hyper-parameter keys of this torch version's Adam param group (amsgrad, foreach, capturable, ...)."""
+    global _ADAM_DEFAULTS
+    if _ADAM_DEFAULTS is None:
+        g = torch.optim.Adam([torch.zeros(1, requires_grad=True)]).param_groups[0]
+        _ADAM_DEFAULTS = {k: v for k, v in g.items() if k != "params"}
+    return _ADAM_DEFAULTS
 
 
 class StepLR:
@@ -121,7 +179,7 @@ class StepLR:
 
     def __init__(self, optimizer, step_size, gamma=0.1):
         self.opt, self.step_size, self.gamma = optimizer, step_size, gamma
-        self.base_lr = optimizer.param_groups[0]["lr"]
+        self.base_lr = optimizer.param_groups[0].setdefault("initial_lr", optimizer.param_groups[0]["lr"])   # as torch does
         self.last_epoch = 0
 
     def step(self):
@@ -129,10 +187,14 @@ class StepLR:
         self.opt.param_groups[0]["lr"] = self.base_lr * self.gamma ** (self.last_epoch // self.step_size)
 
     def state_dict(self):
-        return dict(last_epoch=self.last_epoch, base_lr=self.base_lr, step_size=self.step_size, gamma=self.gamma)
+        """torch.optim.lr_scheduler.StepLR's keys (train.py:37 saves `scheduler.state_dict()`)."""
+        return dict(step_size=self.step_size, gamma=self.gamma, base_lrs=[self.base_lr], last_epoch=self.last_epoch,
+                    _step_count=self.last_epoch + 1, _get_lr_called_within_step=False,
+                    _last_lr=[self.opt.param_groups[0]["lr"]])
 
     def load_state_dict(self, sd):
-        self.__dict__.update({k: sd[k] for k in ("last_epoch", "base_lr", "step_size", "gamma")})
+        self.step_size, self.gamma, self.last_epoch = sd["step_size"], sd["gamma"], sd["last_epoch"]
+        self.base_lr = sd["base_lrs"][0] if "base_lrs" in sd else sd["base_lr"]
 
 
 # ------------------------------------------------------------------------------------------
@@ -228,26 +290,102 @@ def model_from_args(args):
 # checkpoints (train.py:26-81): same dictionary keys, `module.` prefixes stripped on load
 # ------------------------------------------------------------------------------------------
 def save_model(model, optimizer, state, path, scheduler=None):
+    """train.py:26-45: same keys, same value layouts (state dicts of the model / Adam / StepLR, the loop state, the
+    three RNG states), so either side reads the other's files."""
     sd = model.module.state_dict() if hasattr(model, "module") else model.state_dict()
+    if len(os.path.dirname(path)) > 0 and not os.path.exists(os.path.dirname(path)):
+        os.makedirs(os.path.dirname(path))
     ck = {'model_state_dict': sd, 'optimizer_state_dict': optimizer.state_dict() if optimizer is not None else None,
-          'state': state,
-          'random_states': (np.random.get_state(), torch.get_rng_state(),
-                            torch.cuda.get_rng_state() if torch.cuda.is_available() else None)}
+          'state': state}
     if scheduler is not None:
         ck['scheduler_state_dict'] = scheduler.state_dict()
+    ck['random_states'] = (np.random.get_state(), torch.get_rng_state(),
+                           torch.cuda.get_rng_state() if torch.cuda.is_available() else None)
     torch.save(ck, path)
 
 
 def load_model(model, optimizer, path, cuda, device, scheduler=None):
-    ck = torch.load(path, map_location=device, weights_only=False)
+    """train.py:47-81: `module.` prefixes stripped, optimizer / scheduler restored when given, checkpoints that only
+    hold `step` accepted, the numpy / torch / device RNG states restored."""
+    ck = torch.load(path, map_location=device if cuda else 'cpu', weights_only=False)
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in ck['model_state_dict'].items()}
     target = model.module if hasattr(model, "module") else model
     target.load_state_dict(sd)
-    if optimizer is not None and ck.get('optimizer_state_dict') is not None and 'exp_avg' in ck['optimizer_state_dict']:
+    if optimizer is not None:
         optimizer.load_state_dict(ck['optimizer_state_dict'])
-    if scheduler is not None and 'scheduler_state_dict' in ck:
+    if scheduler is not None:
         scheduler.load_state_dict(ck['scheduler_state_dict'])
-    return ck.get('state', {})
+    state = ck['state'] if 'state' in ck else {'step': ck['step']}
+    rs = ck.get('random_states')
+    if rs is not None:
+        np.random.set_state(rs[0])
+        torch.set_rng_state(rs[1].cpu())
+        if torch.cuda.is_available() and rs[2] is not None:
+            torch.cuda.set_rng_state(rs[2].cpu())
+    return state
+
+
+class CheckpointRotation:
+    """The file rotation of the reference's epoch loop (train.py:577-616, 671-684), same file names:
+
+      <model_dir>/checkpoint                              every epoch
+      <model_dir>/checkpoint_best_model                   when the validation loss improves
+      <model_dir>/checkpoint_best_model_of_checkpoint     the previous best, kept when a new best arrives, or the best
+                                                          epoch since that is not the overall best
+      <model_dir>checkpoint_epoch_<E>/...                 every `checkpoint_step` epochs: copies of the above
+                                                          (the reference concatenates without a separator: kept)
+
+    `end_of_epoch` returns True when the epoch set a new best.  The test-set leg of the rotation
+    (`checkpoint_best_model_on_Test`, train.py:623-668) belongs to the metrics row; files that do not
+    exist are skipped by the periodic copy where the reference would stop with FileNotFoundError."""
+
+    def __init__(self, model_dir, model_name, checkpoint_step, start_epoch=0):
+        self.model_dir, self.model_name, self.checkpoint_step = model_dir, model_name, int(checkpoint_step)
+        self.checkpoint_path = os.path.join(model_dir, "checkpoint")
+        self.best_path = os.path.join(model_dir, "checkpoint_best_model")
+        self.best_of_checkpoint_path = os.path.join(model_dir, "checkpoint_best_model_of_checkpoint")
+        self.best_loss_checkpoint = np.inf
+        self.best_epoch_checkpoint = start_epoch
+        self.new_best = False
+
+    def end_of_epoch(self, model, optimizer, scheduler, state, epoch, val_loss, extra_files=()):
+        improved = not (val_loss >= state["best_loss"])
+        if not improved:
+            state["worse_epochs"] += 1
+        else:
+            if self.new_best:
+                self.best_loss_checkpoint = state["best_loss"]
+                self.best_epoch_checkpoint = state["best_epoch"]
+                shutil.copyfile(self.best_path, self.best_of_checkpoint_path)
+            state["worse_epochs"] = 0
+            state["best_loss"] = val_loss
+            state["best_epoch"] = epoch
+            state["best_checkpoint"] = self.best_path
+            self.new_best = True
+            save_model(model, optimizer, state, self.best_path, scheduler)
+        if val_loss < self.best_loss_checkpoint and (val_loss != state["best_loss"] or self.best_loss_checkpoint == np.inf):
+            self.best_loss_checkpoint = val_loss
+            save_model(model, optimizer, state, self.best_of_checkpoint_path, scheduler)
+            self.best_epoch_checkpoint = epoch
+        save_model(model, optimizer, state, self.checkpoint_path, scheduler)
+        if self.checkpoint_step > 0 and epoch % self.checkpoint_step == 0:
+            d = self.model_dir + 'checkpoint_epoch_{}/'.format(epoch)
+            os.makedirs(d, exist_ok=True)
+            copies = [(self.best_path, "checkpoint_best_epoch_{}".format(state["best_epoch"])),
+                      (self.checkpoint_path, "checkpoint_epoch_{}".format(epoch)),
+                      (self.checkpoint_path + '_best_model_on_Test',
+                       "checkpoint_best_model_on_Test_epoch_{}".format(state.get("best_test_epoch", 0))),
+                      (self.best_of_checkpoint_path,
+                       "checkpoint_best_model_checkpoint_epoch_{}".format(self.best_epoch_checkpoint))]
+            copies += [(f, self.model_name + "_" + os.path.basename(f)) for f in extra_files]
+            for src, name in copies:
+                if os.path.isfile(src):
+                    shutil.copyfile(src, d + name)
+        return improved
+
+    def test_leg_done(self):
+        """train.py:669-670: after a test evaluation the 'new best' flag is cleared."""
+        self.new_best = False
 
 
 # ------------------------------------------------------------------------------------------
@@ -355,11 +493,13 @@ def main(args):
 
     model_dir = os.path.join(args.checkpoint_dir, model.model_name)
     os.makedirs(model_dir, exist_ok=True)
-    state = {"step": 0, "worse_epochs": 0, "epochs": 0, "best_loss": np.inf, "best_epoch": 0}
-    ck_path = os.path.join(model_dir, 'checkpoint')
+    state = {"step": 0, "worse_epochs": 0, "epochs": 0, "best_loss": np.inf, "best_epoch": 0, "best_test_epoch": 0}
+    epoch = 0
     if args.load_model is not None and os.path.isfile(args.load_model):
+        print("Continuing training full model from checkpoint " + str(args.load_model))
         state = load_model(model, optimizer, args.load_model, args.use_cuda, device, scheduler)
-    epoch = state["epochs"]
+        epoch = state["epochs"]
+    rotation = CheckpointRotation(model_dir, model.model_name, args.checkpoint_step, start_epoch=epoch)
     while (state["worse_epochs"] < args.patience or epoch < args.min_n_epochs) and not (args.epochs and epoch >= args.epochs):
         epoch += 1
         state["epochs"] += 1
@@ -380,12 +520,8 @@ def main(args):
             scheduler.step()
         print(f"epoch {epoch}: train {float(train_loss):.5f} val {val_loss:.5f} lr {optimizer.param_groups[0]['lr']:.2e} "
               f"({time.time() - t0:.1f}s)")
-        if val_loss >= state["best_loss"]:
-            state["worse_epochs"] += 1
-        else:
-            state["worse_epochs"], state["best_epoch"], state["best_loss"] = 0, epoch, val_loss
-            save_model(model, optimizer, state, ck_path + '_best_model', scheduler)
-        save_model(model, optimizer, state, ck_path, scheduler)
+        if rotation.end_of_epoch(model, optimizer, scheduler, state, epoch, val_loss):
+            print("MODEL IMPROVED ON VALIDATION SET!")
         if args.max_steps and state["step"] >= args.max_steps:
             break
     return state
