@@ -169,8 +169,14 @@ def test_resume_from_reference_checkpoint_matches_reference(golden):
         moved = np.abs(ref_after - ref_before).max()
         assert moved > 0.1 * lr, (name, moved)                      # the step is visible ...
         assert np.abs(got - ref_after).max() < 0.02 * lr, (name, np.abs(got - ref_after).max(), lr)   # ... and matches
+    # every parameter through its checksums.  Adam normalises the step, so an element whose gradient is rounding
+    # noise (sqrt(exp_avg_sq) < 1e-6 here: e.g. two channels of cnn.2.1.bias sit at 1e-9) moves by up to lr in a
+    # direction that depends on the summation order; such elements get a full lr of slack, the others 2 %
+    raw = torch.load(REF_CKPT, map_location="cpu", weights_only=False)["optimizer_state_dict"]["state"]
     names = str(g["param_names"]).split("\n")
-    for (s1, s2), name in zip(g["param_checksums"], names):
+    for i, ((s1, s2), name) in enumerate(zip(g["param_checksums"], names)):
         p = params[name].detach().double()
-        assert abs(p.sum().item() - s1) <= 2e-5 * max(1.0, p.abs().sum().item()), name
-        assert abs((p ** 2).sum().item() - s2) <= 2e-5 * max(1e-6, s2), name
+        noisy = int((raw[i]["exp_avg_sq"].sqrt() < 1e-6).sum()) if i in raw else 0
+        slack = lr * (noisy + 0.02 * p.numel())
+        assert abs(p.sum().item() - s1) <= slack + 1e-6, (name, noisy)
+        assert abs((p ** 2).sum().item() - s2) <= 2 * p.abs().max().item() * slack + 1e-6, (name, noisy)
