@@ -577,6 +577,165 @@ def normalize_dataset(x: np.ndarray, dataset_normalization: str, n_mics: int, do
 
 
 # --------------------------------------------------------------------------------------
+# Post-processing + test metrics  (train.py:84-166, utility_functions.py:184-210,
+# metrics.py:123-208, Dcase21_metrics.py:33-154, 171-221, 239-278)
+# --------------------------------------------------------------------------------------
+METRIC_COUNTERS = ("TP", "FP", "FN", "dc_TP", "dc_FP", "dc_FN", "dc_S", "dc_D", "dc_I", "dc_Nref", "dc_DE_TP", "dc_DE_FP",
+                   "dc_DE_FN")
+
+
+def decode_events(sed: np.ndarray, doa: np.ndarray, max_loc_value=2.0, num_classes=14, max_overlaps=3):
+    """utility_functions.py:184-210 as arrays: active[f, class, event] (np.round != 0, frames whose rounded
+    activities sum to 0 dropped) and the float64 coordinates xyz[f, class, event, 3] = float32(doa * max_loc_value)."""
+    sed = np.asarray(sed)
+    r = np.round(sed)                                           # half to even: 0.5 -> 0
+    active = (r != 0) & (np.sum(r, axis=1, keepdims=True) != 0)
+    xyz = (np.asarray(doa) * max_loc_value).reshape(sed.shape[0], num_classes, max_overlaps, 3)
+    return active.reshape(sed.shape[0], num_classes, max_overlaps), xyz.astype(np.float64)
+
+
+def lsd_counts(act_p, xyz_p, act_t, xyz_t, n_frames, spatial_threshold=2.0):
+    """metrics.py:123-182, literally including its double count: a frame with predictions but no reference adds its
+    predictions to FP twice (once in the `len(t) == 0` branch, once in the unconditional tail), a frame with
+    references but no prediction adds them to FN twice; otherwise a reference event is matched when ANY prediction of
+    its class lies closer than the threshold, FN += n_t - matched, FP += n_p - matched (which can be negative)."""
+    if act_p.shape[0] > n_frames or act_t.shape[0] > n_frames:
+        raise KeyError("event beyond n_frames")                 # frames[i[0]] in the reference
+    TP = FP = FN = 0
+    for f in range(act_p.shape[0]):
+        n_p, n_t = int(act_p[f].sum()), int(act_t[f].sum())
+        if n_t == 0:
+            FP += 2 * n_p
+            continue
+        if n_p == 0:
+            FN += 2 * n_t
+            continue
+        matched = 0
+        for c, e in zip(*np.nonzero(act_t[f])):
+            cand = np.nonzero(act_p[f, c])[0]
+            if any(np.linalg.norm(xyz_t[f, c, e] - xyz_p[f, c, k]) < spatial_threshold for k in cand):
+                matched += 1
+        TP += matched
+        FN += n_t - matched
+        FP += n_p - matched
+    return TP, FP, FN
+
+
+def _angular_distance_deg(a, b):
+    """Dcase21_metrics.py:171-188 for one pair of Cartesian vectors (float64)."""
+    n1 = np.sqrt(a[0] ** 2 + a[1] ** 2 + a[2] ** 2 + 1e-10)
+    n2 = np.sqrt(b[0] ** 2 + b[1] ** 2 + b[2] ** 2 + 1e-10)
+    d = (a[0] / n1) * (b[0] / n2) + (a[1] / n1) * (b[1] / n2) + (a[2] / n1) * (b[2] / n2)
+    return np.arccos(np.clip(d, -1, 1)) * 180 / np.pi
+
+
+def dcase_counts(act_p, xyz_p, act_t, xyz_t, max_frames, doa_threshold=20, frames_per_block=10):
+    """segment_labels (Dcase21_metrics.py:239-278) + SELDMetrics.update_seld_scores (:51-154) for one recording,
+    on the arrays of `decode_events`.  Returns the increments of the class's counters and of `_total_DE`."""
+    from scipy.optimize import linear_sum_assignment
+    n_cls = act_p.shape[1]
+    c = dict(TP=0, FP=0, FN=0, S=0, D=0, I=0, Nref=0, DE_TP=0, DE_FP=0, DE_FN=0)
+    total_de = 0.0
+    for start in range(0, max_frames, frames_per_block):
+        frames = [f for f in range(start, start + frames_per_block) if f < act_p.shape[0]]
+        loc_fn = loc_fp = 0
+        for k in range(n_cls):
+            g_cnt = [int(act_t[f, k].sum()) for f in frames]
+            p_cnt = [int(act_p[f, k].sum()) for f in frames]
+            nb_gt, nb_pred = max(g_cnt, default=0), max(p_cnt, default=0)
+            c["Nref"] += nb_gt
+            if nb_gt and nb_pred:
+                track_sum, track_n = {}, {}
+                for f, g, p in zip(frames, g_cnt, p_cnt):
+                    if not (g and p):
+                        continue
+                    gt = xyz_t[f, k][act_t[f, k]]
+                    pr = xyz_p[f, k][act_p[f, k]]
+                    cost = np.array([[_angular_distance_deg(a, b) for b in pr] for a in gt])
+                    rows, cols = linear_sum_assignment(cost)
+                    for r, col in zip(rows, cols):
+                        track_sum[r] = track_sum.get(r, 0) + cost[r, col]
+                        track_n[r] = track_n.get(r, 0) + 1
+                if not track_sum:
+                    loc_fn += nb_pred
+                    c["FN"] += nb_pred
+                    c["DE_FN"] += nb_pred
+                else:
+                    for r in track_sum:
+                        avg = track_sum[r] / track_n[r]
+                        total_de += avg
+                        c["DE_TP"] += 1
+                        if avg <= doa_threshold:
+                            c["TP"] += 1
+                        else:
+                            loc_fp += 1
+                            c["FP"] += 1
+                    if nb_pred > nb_gt:
+                        loc_fp += nb_pred - nb_gt
+                        c["FP"] += nb_pred - nb_gt
+                        c["DE_FP"] += nb_pred - nb_gt
+                    elif nb_pred < nb_gt:
+                        loc_fn += nb_gt - nb_pred
+                        c["FN"] += nb_gt - nb_pred
+                        c["DE_FN"] += nb_gt - nb_pred
+            elif nb_gt:
+                loc_fn += nb_gt
+                c["FN"] += nb_gt
+                c["DE_FN"] += nb_gt
+            elif nb_pred:
+                loc_fp += nb_pred
+                c["FP"] += nb_pred
+                c["DE_FP"] += nb_pred
+        c["S"] += min(loc_fp, loc_fn)
+        c["D"] += max(0, loc_fn - loc_fp)
+        c["I"] += max(0, loc_fp - loc_fn)
+    return c, total_de
+
+
+def test_results(counts: dict, total_de: float, epoch=0):
+    """The 16 numbers evaluate_test returns (train.py:131-150) from the accumulated counters
+    (`compute_seld_scores`, Dcase21_metrics.py:33-49, inlined)."""
+    import sys
+    eps_f, eps = sys.float_info.epsilon, np.finfo(float).eps
+    TP, FP, FN = counts["TP"], counts["FP"], counts["FN"]
+    precision = TP / (TP + FP + eps_f)
+    recall = TP / (TP + FN + eps_f)
+    F_score = 2 * ((precision * recall) / (precision + recall + eps_f))
+    Nref, Nsys = TP + FN, TP + FP
+    ER_score = (max(Nref, Nsys) - TP) / (Nref + 0.0)
+    ER = (counts["dc_S"] + counts["dc_D"] + counts["dc_I"]) / float(counts["dc_Nref"] + eps)
+    F = counts["dc_TP"] / (eps + counts["dc_TP"] + 0.5 * (counts["dc_FP"] + counts["dc_FN"]))
+    LE = total_de / float(counts["dc_DE_TP"] + eps) if counts["dc_DE_TP"] else 180
+    LR = counts["dc_DE_TP"] / (eps + counts["dc_DE_TP"] + counts["dc_DE_FN"])
+    SELD_dcase21 = np.mean([ER, 1 - F, LE / 180, 1 - LR])
+    SELD_L3DAS21_LRLE = np.mean([ER_score, 1 - F_score, LE / 180, 1 - LR])
+    CSL_score = np.mean([LE / 180, 1 - LR])
+    LSD_score = np.mean([1 - F_score, ER_score])
+    return [epoch, F_score, ER_score, precision, recall, TP, FP, FN, CSL_score, LSD_score, SELD_L3DAS21_LRLE, SELD_dcase21,
+            ER, F, LE, LR]
+
+
+def evaluate_clips(sed, doa, target, num_frames=600, max_loc_value=2.0, spatial_threshold=2.0, doa_threshold=20,
+                   num_classes=14, max_overlaps=3, epoch=0):
+    """train.py:84-150 after the model call: sed (clips, T, 42), doa (clips, T, 126), target (clips, T, 168)."""
+    counts = {k: 0 for k in METRIC_COUNTERS}
+    total_de = 0.0
+    n = num_classes * max_overlaps
+    for s, d, t in zip(sed, doa, target):
+        ap, xp = decode_events(s, d, max_loc_value, num_classes, max_overlaps)
+        at, xt = decode_events(t[:, :n], t[:, n:], max_loc_value, num_classes, max_overlaps)
+        tp, fp, fn = lsd_counts(ap, xp, at, xt, num_frames, spatial_threshold)
+        counts["TP"] += tp
+        counts["FP"] += fp
+        counts["FN"] += fn
+        c, de = dcase_counts(ap, xp, at, xt, num_frames, doa_threshold)
+        for k, v in c.items():
+            counts["dc_" + k] += v
+        total_de += de
+    return test_results(counts, total_de, epoch), counts, total_de
+
+
+# --------------------------------------------------------------------------------------
 # Deterministic fills shared by the fixture generator, the tests and the HIP model
 # --------------------------------------------------------------------------------------
 def closed_form_fill_(named_tensors, amp=0.3):

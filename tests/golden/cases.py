@@ -150,3 +150,35 @@ def norm_input(shape, dtype, salt):
     n = np.arange(int(np.prod(shape)), dtype=np.float64)
     v = 0.7 + np.sin(0.37 * n + salt) * 0.5 + 0.3 * np.cos(0.0113 * n * (salt + 1)) + 0.002 * (n % 97)
     return v.reshape(shape).astype(dtype)
+
+
+# post-processing + test metrics: metrics.npz holds what the reference's evaluate_test and its
+# metric classes return for these inputs
+METRIC_CASES = [
+    # name, clips, frames (= num_frames), seed, variant
+    ("mixed600", 3, 600, 11, "mixed"),
+    ("short47", 2, 47, 12, "mixed"),
+    ("no_pred", 1, 100, 13, "no_pred"),
+    ("half_silent", 2, 120, 14, "half_silent"),
+    ("crowded", 1, 80, 15, "crowded"),
+]
+
+
+def metric_inputs(clips, frames, seed, variant, n_cls=14, n_ov=3):
+    """(sed, doa, target) float32: sed (clips, T, 42) in [0, 1], doa (clips, T, 126) in about [-1, 1],
+    target (clips, T, 168) = [activity {0, 1} | location].  numpy's PCG64 streams are stable across versions."""
+    rng = np.random.default_rng(seed)
+    n = n_cls * n_ov
+    density = 0.3 if variant == "crowded" else 0.08
+    act = rng.random((clips, frames, n)) < density
+    if variant == "half_silent":
+        act[:, frames // 2:] = False
+    loc = rng.uniform(-1, 1, (clips, frames, n, 3))
+    sed = np.where(act, rng.uniform(0.3, 1.0, act.shape), rng.uniform(0.0, 0.56, act.shape))
+    sed[rng.random(act.shape) < 0.01] = 0.5                          # exactly on the rounding boundary
+    if variant == "no_pred":
+        sed = sed * 0.49
+    noise = rng.normal(0, 0.15, loc.shape) + (rng.random(act.shape) < 0.2)[..., None] * rng.normal(0, 1.0, loc.shape)
+    doa = loc + noise
+    target = np.concatenate([act.astype(np.float32), (loc * act[..., None]).reshape(clips, frames, n * 3).astype(np.float32)], axis=2)
+    return sed.astype(np.float32), doa.reshape(clips, frames, n * 3).astype(np.float32), target.astype(np.float32)

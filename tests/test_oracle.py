@@ -193,3 +193,21 @@ def test_dataset_normalisation_matches_reference(golden):
     ieee, ref = O.dq_unit_norm_ieee(x), g["unit_f32.0"]
     assert np.array_equal(ieee[:, 4:], ref[:, 4:])
     assert np.abs(ieee[:, :4] - ref[:, :4]).max() <= np.spacing(np.float32(1.0))
+
+
+def test_test_metrics_match_reference(golden):
+    """metrics.npz = the reference's evaluate_test results and the counters of its metric classes
+    (make_golden.gen_metrics).  Counters exact, floating-point results to 1e-12."""
+    from tests.golden.cases import METRIC_CASES, metric_inputs
+    g = golden("metrics")
+    for name, clips, frames, seed, variant in METRIC_CASES:
+        sed, doa, target = metric_inputs(clips, frames, seed, variant)
+        results, counts, total_de = O.evaluate_clips(sed, doa, target, num_frames=frames, epoch=7)
+        assert [counts[k] for k in O.METRIC_COUNTERS] == g[name + ".counters"].tolist(), name
+        assert abs(total_de - g[name + ".total_DE"][0]) <= 1e-12 * max(1.0, total_de), name
+        assert np.allclose(np.array(results, dtype=np.float64), g[name + ".results"], rtol=1e-12, atol=1e-12), name
+    # no reference event at all: the reference divides by Nref = 0 (train.py:136)
+    sed, doa, target = metric_inputs(1, 20, 3, "mixed")
+    target[:] = 0
+    with pytest.raises(ZeroDivisionError):
+        O.evaluate_clips(sed, doa, target, num_frames=20)
