@@ -340,6 +340,28 @@ int seld_dq_unit_norm(float* x, int64_t items, int32_t channels, int64_t hw, voi
 int seld_group_standardize(float* x, int64_t items, int32_t channels, int32_t c0, int32_t c1, int64_t hw,
                            double* work, float* mean_std, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Post-processing + test metrics of evaluate_test (train.py:84-130) for a batch of
+ * recordings whose outputs are resident: sed (clips, frames, classes*overlaps), doa (clips, frames,
+ * 3*classes*overlaps), target (clips, frames, 4*classes*overlaps) = [activity | location] as the
+ * reference's joint target.  One call replaces, per recording, gen_submission_list_task2
+ * (utility_functions.py:184-210) on prediction and target, location_sensitive_detection
+ * (metrics.py:123-182), segment_labels (Dcase21_metrics.py:239-278) and
+ * SELDMetrics.update_seld_scores (Dcase21_metrics.py:51-154), and ADDS to
+ *   counters[13] = { TP, FP, FN (L3DAS21, summed as train.py:124-126) ;
+ *                    _TP, _FP, _FN, _S, _D, _I, _Nref, _DE_TP, _DE_FP, _DE_FN of SELDMetrics }
+ *   total_de[1]  = SELDMetrics._total_DE
+ * (device memory, zeroed by the caller before the first recording).  The scores of train.py:131-150 /
+ * compute_seld_scores are a dozen scalar operations on these and stay on the host.
+ * frames > num_frames is SELD_EINVAL; overlaps > 3, classes*overlaps > 64 or frames_per_block > 16 are
+ * SELD_EUNSUPPORTED (the reference uses 14 x 3 and 10).
+ * ------------------------------------------------------------------------------------------ */
+#define SELD_METRIC_COUNTERS 13
+int seld_metrics_accumulate(const float* sed, const float* doa, const float* target, int32_t clips, int32_t frames,
+                            int32_t num_frames, int32_t classes, int32_t overlaps, float max_loc_value,
+                            double spatial_threshold, double doa_threshold, int32_t frames_per_block,
+                            int64_t* counters, double* total_de, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

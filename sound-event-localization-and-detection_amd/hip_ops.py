@@ -1035,6 +1035,38 @@ def group_standardize_(x, c0, c1):
     return mean_std
 
 
+
+METRIC_COUNTERS = ("TP", "FP", "FN", "dc_TP", "dc_FP", "dc_FN", "dc_S", "dc_D", "dc_I", "dc_Nref", "dc_DE_TP", "dc_DE_FP",
+                   "dc_DE_FN")
+
+
+def metrics_new(device):
+    """Zeroed accumulators for `metrics_accumulate`: (13 int64 counters, 1 double)."""
+    return (torch.zeros(len(METRIC_COUNTERS), device=device, dtype=torch.int64),
+            torch.zeros(1, device=device, dtype=torch.float64))
+
+
+def metrics_accumulate(acc, sed, doa, target, num_frames, num_classes=14, max_overlaps=3, max_loc_value=2.0,
+                       spatial_threshold=2.0, doa_threshold=20, frames_per_block=10):
+    """Decode + L3DAS21 / DCASE21 counters of a batch of recordings (train.py:100-126), added to `acc`."""
+    sed, doa, target = _req(sed, "sed"), _req(doa, "doa"), _req(target, "target")
+    n = num_classes * max_overlaps
+    if sed.dim() == 2:
+        sed, doa, target = sed[None], doa[None], target[None]
+    clips, frames = sed.shape[0], sed.shape[1]
+    if tuple(sed.shape) != (clips, frames, n) or tuple(doa.shape) != (clips, frames, 3 * n) or \
+            tuple(target.shape) != (clips, frames, 4 * n):
+        raise L.SeldHipError(f"metrics_accumulate: shapes {tuple(sed.shape)} / {tuple(doa.shape)} / {tuple(target.shape)} do not "
+                             f"match (clips, frames, {n}) / (.., {3 * n}) / (.., {4 * n})")
+    counters, total_de = acc
+    L.check(L.lib().seld_metrics_accumulate(L.ptr(sed), L.ptr(doa), L.ptr(target), clips, frames, int(num_frames),
+                                            int(num_classes), int(max_overlaps), ctypes.c_float(max_loc_value),
+                                            ctypes.c_double(spatial_threshold), ctypes.c_double(doa_threshold),
+                                            int(frames_per_block), L.ptr(counters), L.ptr(total_de), L.current_stream()),
+            "seld_metrics_accumulate")
+    return acc
+
+
 _identity_cache = {}
 
 

@@ -451,6 +451,51 @@ def normalize_dataset(args, *predictors):
     return desc
 
 
+def test_results_from_counters(counts, total_de, epoch=0):
+    """The 16 numbers of train.py:131-150 (with compute_seld_scores, Dcase21_metrics.py:33-49) from the counters."""
+    eps_f, eps = sys.float_info.epsilon, np.finfo(float).eps
+    TP, FP, FN = counts["TP"], counts["FP"], counts["FN"]
+    precision = TP / (TP + FP + eps_f)
+    recall = TP / (TP + FN + eps_f)
+    F_score = 2 * ((precision * recall) / (precision + recall + eps_f))
+    Nref, Nsys = TP + FN, TP + FP
+    ER_score = (max(Nref, Nsys) - TP) / (Nref + 0.0)          # ZeroDivisionError without a reference event, as the reference
+    ER_dcase21 = (counts["dc_S"] + counts["dc_D"] + counts["dc_I"]) / float(counts["dc_Nref"] + eps)
+    F_dcase21 = counts["dc_TP"] / (eps + counts["dc_TP"] + 0.5 * (counts["dc_FP"] + counts["dc_FN"]))
+    LE_dcase21 = total_de / float(counts["dc_DE_TP"] + eps) if counts["dc_DE_TP"] else 180
+    LR_dcase21 = counts["dc_DE_TP"] / (eps + counts["dc_DE_TP"] + counts["dc_DE_FN"])
+    SELD_dcase21 = np.mean([ER_dcase21, 1 - F_dcase21, LE_dcase21 / 180, 1 - LR_dcase21])
+    SELD_L3DAS21_LRLE = np.mean([ER_score, 1 - F_score, LE_dcase21 / 180, 1 - LR_dcase21])
+    CSL_score = np.mean([LE_dcase21 / 180, 1 - LR_dcase21])
+    LSD_score = np.mean([1 - F_score, ER_score])
+    return [epoch, F_score, ER_score, precision, recall, TP, FP, FN, CSL_score, LSD_score, SELD_L3DAS21_LRLE, SELD_dcase21,
+            ER_dcase21, F_dcase21, LE_dcase21, LR_dcase21]
+
+
+def evaluate_test(model, device, dataloader, epoch=0, max_loc_value=2., num_frames=600, spatial_threshold=2., args=None):
+    """train.py:84-166: same arguments, same 16-entry result list.  The network outputs never leave the device: each
+    batch's decode + counting is one kernel (hip_ops.metrics_accumulate) and the counters are read back once."""
+    output_classes = args.output_classes if args is not None else 14
+    class_overlaps = args.class_overlaps if args is not None else 3
+    doa_threshold = args.Dcase21_metrics_DOA_threshold if args is not None else 20
+    model.eval()
+    acc = H.metrics_new(device)
+    with torch.no_grad():
+        for x, target in dataloader:
+            sed, doa = model(x.to(device))
+            # gen_submission_list_task2 is called with its default num_classes = 14 (train.py:110-116)
+            H.metrics_accumulate(acc, sed, doa, target.to(device), num_frames, 14, class_overlaps, max_loc_value,
+                                 spatial_threshold, doa_threshold)
+    counts = dict(zip(H.METRIC_COUNTERS, acc[0].cpu().tolist()))
+    results = test_results_from_counters(counts, float(acc[1].item()), epoch)
+    print('*******************************\nRESULTS')
+    for label, v in (('TP: ', results[5]), ('FP: ', results[6]), ('FN: ', results[7]), ('Global SELD score: ', results[10]),
+                     ('LSD score: ', results[9]), ('CSL score: ', results[8]), ('F score: ', results[1]),
+                     ('ER score: ', results[2]), ('LE: ', results[14]), ('LR: ', results[15])):
+        print(label, v)
+    return results
+
+
 def evaluate(model, device, criterion_sed, criterion_doa, loader, args):
     """Mean loss over a loader, no grad (train.py:168-183)."""
     model.eval()
