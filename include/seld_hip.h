@@ -353,7 +353,7 @@ int seld_group_standardize(float* x, int64_t items, int32_t channels, int32_t c0
  *   total_de[1]  = SELDMetrics._total_DE
  * (device memory, zeroed by the caller before the first recording).  The scores of train.py:131-150 /
  * compute_seld_scores are a dozen scalar operations on these and stay on the host.
- * frames > num_frames is SELD_EINVAL; overlaps > 3, classes*overlaps > 64 or frames_per_block > 16 are
+ * frames > num_frames is SELD_EINVAL; overlaps > 3, classes*overlaps > 64 or frames_per_block > 64 are
  * SELD_EUNSUPPORTED (the reference uses 14 x 3 and 10).
  * ------------------------------------------------------------------------------------------ */
 #define SELD_METRIC_COUNTERS 13

@@ -383,9 +383,31 @@ class CheckpointRotation:
                     shutil.copyfile(src, d + name)
         return improved
 
-    def test_leg_done(self):
-        """train.py:669-670: after a test evaluation the 'new best' flag is cleared."""
+    def test_checkpoint(self, test_mode):
+        """train.py:626-642: which checkpoint the test leg evaluates and the epoch it reports: the best model when this
+        epoch set a new best, else the best-of-checkpoint model ('test_best' mode); the live model otherwise (None)."""
+        if test_mode != 'test_best':
+            return None, None
+        if self.new_best:
+            return self.best_path, None                 # epoch = state['best_epoch'] after loading
+        return self.best_of_checkpoint_path, self.best_epoch_checkpoint
+
+    def after_test(self, model, optimizer, scheduler, state, epoch, test_results, test_mode):
+        """train.py:655-670: keep `checkpoint_best_model_on_Test` when the Global SELD score (entry 10 of the results)
+        is not worse than the best seen, then clear the 'new best' flag.  Returns True when it saved."""
+        if not hasattr(self, "best_test_metric"):
+            self.best_test_metric = 1
+        saved = False
+        if test_results[10] <= self.best_test_metric:
+            self.best_test_metric = test_results[10]
+            if test_mode == 'test_best':
+                state["best_test_epoch"] = state["best_epoch"] if self.new_best else self.best_epoch_checkpoint
+            else:
+                state["best_test_epoch"] = epoch
+            save_model(model, optimizer, state, self.checkpoint_path + '_best_model_on_Test', scheduler)
+            saved = True
         self.new_best = False
+        return saved
 
 
 # ------------------------------------------------------------------------------------------
@@ -526,6 +548,7 @@ def main(args):
         data = [synthetic_batch(args.batch_size, args.input_channels, args.freq_dim, args.time_dim, n_out, 1234 + i, device)
                 for i in range(args.synthetic)]
         tr_data, val_data = data, data[:1]
+        test_data = None
     else:
         xs, ys = load_pickled(args.training_predictors_path, args.training_target_path)
         xv, yv = load_pickled(args.validation_predictors_path, args.validation_target_path)
@@ -535,6 +558,12 @@ def main(args):
                                               pin_memory=False)
         val_data = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xv, yv), args.batch_size, shuffle=False,
                                                pin_memory=False)
+        test_data = None
+        if os.path.isfile(str(args.test_predictors_path)) and os.path.isfile(str(args.test_target_path)):
+            xt, yt = load_pickled(args.test_predictors_path, args.test_target_path)
+            xt = xt.to(device)
+            print(normalize_dataset(args, xt))
+            test_data = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xt, yt), 1, shuffle=False)
 
     model_dir = os.path.join(args.checkpoint_dir, model.model_name)
     os.makedirs(model_dir, exist_ok=True)
@@ -567,6 +596,20 @@ def main(args):
               f"({time.time() - t0:.1f}s)")
         if rotation.end_of_epoch(model, optimizer, scheduler, state, epoch, val_loss):
             print("MODEL IMPROVED ON VALIDATION SET!")
+        if test_data is not None and args.test_step > 0 and epoch % args.test_step == 0:      # train.py:623-670
+            path, at_epoch = rotation.test_checkpoint(args.test_mode)
+            if path is not None:
+                live = os.path.join(model_dir, "checkpoint")
+                state = load_model(model, optimizer, path, args.use_cuda, device, scheduler)
+                at_epoch = state['best_epoch'] if at_epoch is None else at_epoch
+            results = evaluate_test(model, device, test_data, epoch=epoch if path is None else at_epoch,
+                                    max_loc_value=args.max_loc_value, num_frames=args.num_frames,
+                                    spatial_threshold=args.spatial_threshold, args=args)
+            rotation.after_test(model, optimizer, scheduler, state, epoch, results, args.test_mode)
+            if path is not None:
+                # the reference reloads args.load_model here (train.py:667), which only exists when resuming; the live
+                # checkpoint of this epoch is what training must continue from
+                state = load_model(model, optimizer, live, args.use_cuda, device, scheduler)
         if args.max_steps and state["step"] >= args.max_steps:
             break
     return state

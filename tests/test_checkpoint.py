@@ -180,3 +180,70 @@ def test_resume_from_reference_checkpoint_matches_reference(golden):
         slack = lr * (noisy + 0.02 * p.numel())
         assert abs(p.sum().item() - s1) <= slack + 1e-6, (name, noisy)
         assert abs((p ** 2).sum().item() - s2) <= 2 * p.abs().max().item() * slack + 1e-6, (name, noisy)
+
+
+def test_after_test_keeps_best_model_on_test(tmp_path):
+    """train.py:655-670 by hand: a Global SELD of 0.8 (<= 1) saves, 0.9 does not, 0.8 again (<=) saves; 'test_best'
+    mode reports the best epoch while the 'new best' flag is up and the best-of-checkpoint epoch afterwards."""
+    T = pkg().train
+    model = torch.nn.Linear(4, 3)
+    opt = T.FlatAdam(model.parameters(), lr=1e-3)
+    rot = T.CheckpointRotation(str(tmp_path / "toy"), "toy", checkpoint_step=0)
+    state = {"step": 0, "worse_epochs": 0, "epochs": 1, "best_loss": np.inf, "best_epoch": 0, "best_test_epoch": 0}
+    rot.end_of_epoch(model, opt, None, state, 1, 2.0)
+    assert rot.test_checkpoint("test_best") == (rot.best_path, None)
+    res = [0.0] * 16
+    res[10] = 0.8
+    assert rot.after_test(model, opt, None, state, 1, res, "test_best") and state["best_test_epoch"] == 1
+    assert os.path.isfile(rot.checkpoint_path + "_best_model_on_Test") and rot.new_best is False
+    assert rot.test_checkpoint("test_best") == (rot.best_of_checkpoint_path, 1)
+    assert rot.test_checkpoint("test_last") == (None, None)
+    res[10] = 0.9
+    assert not rot.after_test(model, opt, None, state, 2, res, "test_last")
+    res[10] = 0.8
+    assert rot.after_test(model, opt, None, state, 3, res, "test_last") and state["best_test_epoch"] == 3
+
+
+@pytest.mark.gpu
+def test_main_runs_the_reference_loop_end_to_end(tmp_path):
+    """train.main on pickled arrays: device-side normalisation, two epochs of training, validation, the test leg with the
+    device metrics every epoch, the reference's checkpoint files; then a resume from the last checkpoint."""
+    import pickle
+    T = pkg().train
+    rng = np.random.default_rng(5)
+    paths = {}
+    for split, n in (("training", 4), ("validation", 2), ("test", 2)):
+        x = (rng.random((n, 8, 128, 64)) + 0.05).astype(np.float32)
+        act = (rng.random((n, 8, 42)) < 0.15).astype(np.float32)
+        loc = rng.uniform(-1, 1, (n, 8, 126)).astype(np.float32) * np.repeat(act, 3, axis=2)
+        y = np.concatenate([act, loc], axis=2)
+        y[:, 0, 0] = 1.0                                  # at least one reference event (train.py:136 divides by Nref)
+        for kind, arr in (("predictors", x), ("target", y)):
+            paths[f"{split}_{kind}_path"] = str(tmp_path / f"{split}_{kind}.pkl")
+            pickle.dump(arr, open(paths[f"{split}_{kind}_path"], "wb"))
+    flags = dict(paths, results_path=str(tmp_path / "res"), checkpoint_dir=str(tmp_path / "ck"), use_cuda="True", gpu_id=0,
+                 batch_size=2, epochs=2, min_n_epochs=2, patience=1, test_step=1, checkpoint_step=2, test_mode="test_best",
+                 num_frames=8, dataset_normalization="UnitNorm", n_mics=2, domain="DQ", domain_classifier="DQ", phase="False",
+                 input_channels=8, time_dim=64, freq_dim=128, output_classes=14, class_overlaps=3,
+                 cnn_filters="[16, 16, 16]", pool_size="[[8, 2], [8, 2], [2, 2]]", pool_time="TCN", D="[10]",
+                 dilation_mode="fibonacci", G=32, U=16, V="[16, 16]", V_kernel_size=3, fc_layers="[16]",
+                 fc_activations="linear", fc_dropout="Last", use_bias_conv="False", use_bias_linear="True", batch_norm="BN",
+                 dropout_perc=0.0, spatial_dropout_rate=0.0, lr=1e-3, use_lr_scheduler="True", lr_scheduler_step_size=1,
+                 lr_scheduler_gamma=0.5, min_lr=1e-6, TextArgs="none")
+    args = T.parse_args([f"--{k}={v}" for k, v in flags.items()])
+    state = T.main(args)
+    assert state["epochs"] == 2 and state["step"] == 4 and np.isfinite(state["best_loss"])
+    ck_root = str(tmp_path / "ck")
+    model_dirs = [d for d in os.listdir(ck_root) if os.path.isdir(os.path.join(ck_root, d)) and "checkpoint_epoch" not in d]
+    assert len(model_dirs) == 1
+    md = os.path.join(ck_root, model_dirs[0])
+    files = set(os.listdir(md))
+    assert {"checkpoint", "checkpoint_best_model", "checkpoint_best_model_of_checkpoint", "checkpoint_best_model_on_Test"} <= files
+    periodic = md + "checkpoint_epoch_2/"
+    assert os.path.isdir(periodic) and "checkpoint_epoch_2" in os.listdir(periodic)
+    last = torch.load(os.path.join(md, "checkpoint"), map_location="cpu", weights_only=False)
+    assert last["state"]["epochs"] == 2 and abs(last["optimizer_state_dict"]["param_groups"][0]["lr"] - 2.5e-4) < 1e-12
+    # resume: one more epoch from the stored state
+    flags.update(load_model=os.path.join(md, "checkpoint"), epochs=3, min_n_epochs=3)
+    state2 = T.main(T.parse_args([f"--{k}={v}" for k, v in flags.items()]))
+    assert state2["epochs"] == 3 and state2["step"] == 6
