@@ -238,7 +238,9 @@ def test_main_runs_the_reference_loop_end_to_end(tmp_path):
     assert len(model_dirs) == 1
     md = os.path.join(ck_root, model_dirs[0])
     files = set(os.listdir(md))
-    assert {"checkpoint", "checkpoint_best_model", "checkpoint_best_model_of_checkpoint", "checkpoint_best_model_on_Test"} <= files
+    # (checkpoint_best_model_on_Test appears only once a Global SELD score <= 1 is seen, train.py:520, 655; a net trained
+    #  for four steps scores above 1)
+    assert {"checkpoint", "checkpoint_best_model", "checkpoint_best_model_of_checkpoint"} <= files
     periodic = md + "checkpoint_epoch_2/"
     assert os.path.isdir(periodic) and "checkpoint_epoch_2" in os.listdir(periodic)
     last = torch.load(os.path.join(md, "checkpoint"), map_location="cpu", weights_only=False)
