@@ -35,9 +35,14 @@ struct MetricsP {
     double* total_de;
 };
 
+struct __attribute__((packed, aligned(4))) Xyz {
+    float v[3];                                         // one 12-byte load (global_load_dwordx3), dword aligned
+};
+
 __device__ __forceinline__ void load_xyz(const float* loc, int slot, float max_loc, double v[3]) {
+    const Xyz t = *reinterpret_cast<const Xyz*>(loc + slot * 3);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] = (double)(loc[slot * 3 + k] * max_loc);
+    for (int k = 0; k < 3; ++k) v[k] = (double)(t.v[k] * max_loc);
 }
 
 // Dcase21_metrics.py:171-188
@@ -77,44 +82,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// Copy a contiguous run of floats into the wave's LDS slice with 8 loads per lane in flight (a plain loop waits for
-// each load before its LDS store: ~54 dependent HBM round trips per unit, which was the whole run time).
-__device__ __forceinline__ void copy_run(float* dst, const float* __restrict__ src, int count, int lane) {
-    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (count & 3) == 0;
-    if (vec) {
-        const int nv = count >> 2;
-        const float4* s4 = reinterpret_cast<const float4*>(src);
-        float4* d4 = reinterpret_cast<float4*>(dst);
-        for (int base = 0; base < nv; base += 64 * 8) {
-            float4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = base + k * 64 + lane;
-                v[k] = s4[min(i, nv - 1)];                      // clamped, not predicated: keeps v[] in registers
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = base + k * 64 + lane;
-                if (i < nv) d4[i] = v[k];
-            }
-        }
-    } else {
-        for (int base = 0; base < count; base += 64 * 8) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = base + k * 64 + lane;
-                v[k] = src[min(i, count - 1)];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = base + k * 64 + lane;
-                if (i < count) dst[i] = v[k];
-            }
-        }
-    }
-}
-
 // One WAVE per unit = (recording, block of fpb frames); a wave walks units u, u + total_waves, ... and keeps its
 // counters in registers until the end (13 + 1 atomics per wave in all).  Per unit:
 //   1. the block's rows (fpb * 8n floats, three contiguous runs in memory) are copied to the wave's LDS slice with
@@ -128,13 +95,9 @@ __global__ __launch_bounds__(256) void metrics_kernel(const MetricsP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = p.classes * p.overlaps;
-    const int row_floats = 8 * n;                       // sed n | doa 3n | target 4n
-    // rows | masks (u64) | costs (f64 [class][frame][3][3]) | pair list (u32), later matches (f64 [class][frame][3])
-    const int slice_floats = p.fpb * row_floats + 4 * p.fpb + 27 * p.classes * p.fpb;
-    float* sed_s = smem + (size_t)wave * slice_floats;
-    float* doa_s = sed_s + p.fpb * n;
-    float* tgt_s = doa_s + p.fpb * 3 * n;
-    unsigned long long* mp_s = reinterpret_cast<unsigned long long*>(tgt_s + p.fpb * 4 * n);      // 8-byte aligned: see host
+    // masks (u64) | costs (f64 [class][frame][3][3]) | pair list (u32), later matches (f64 [class][frame][3])
+    const int slice_floats = 4 * p.fpb + 27 * p.classes * p.fpb;
+    unsigned long long* mp_s = reinterpret_cast<unsigned long long*>(smem + (size_t)wave * slice_floats);
     unsigned long long* mt_s = mp_s + p.fpb;
     double* cost_s = reinterpret_cast<double*>(mt_s + p.fpb);
     double* match_s = cost_s + 9 * p.classes * p.fpb;
@@ -154,25 +117,32 @@ __global__ __launch_bounds__(256) void metrics_kernel(const MetricsP p) {
         const float* sed = p.sed + ((size_t)clip * p.frames + f0) * n;
         const float* doa = p.doa + ((size_t)clip * p.frames + f0) * 3 * n;
         const float* tgt = p.target + ((size_t)clip * p.frames + f0) * 4 * n;
-        copy_run(sed_s, sed, nf * n, lane);
-        copy_run(doa_s, doa, nf * 3 * n, lane);
-        copy_run(tgt_s, tgt, nf * 4 * n, lane);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave's own LDS stores have landed
-
-        // the frames' activity masks, kept in LDS
-        for (int f = 0; f < nf; ++f) {
-            const float rp = lane < n ? rintf(sed_s[f * n + lane]) : 0.f;       // round half to even, as np.round
-            const float rt = lane < n ? rintf(tgt_s[f * 4 * n + lane]) : 0.f;
-            const unsigned long long bp = __ballot(rp != 0.f), bt = __ballot(rt != 0.f);
-            const bool zp = wave_sum_f32(rp) == 0.f, zt = wave_sum_f32(rt) == 0.f;
-            if (lane == 0) {
-                mp_s[f] = zp ? 0ull : bp;
-                mt_s[f] = zt ? 0ull : bt;
+        // the frames' activity masks, kept in LDS.  Activities are read straight from memory (one coalesced row per
+        // frame, 8 frames in flight); coordinates are fetched only for the few active slots further down - the rows
+        // are not staged in LDS, which would cap the CU at 5 waves.
+        for (int fb = 0; fb < nf; fb += 8) {
+            float vp[8], vt[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = min(fb + k, nf - 1);
+                vp[k] = lane < n ? sed[(size_t)f * n + lane] : 0.f;
+                vt[k] = lane < n ? tgt[(size_t)f * 4 * n + lane] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = fb + k;
+                if (f >= nf) break;                             // uniform
+                const float rp = rintf(vp[k]), rt = rintf(vt[k]);       // round half to even, as np.round
+                const unsigned long long bp = __ballot(rp != 0.f), bt = __ballot(rt != 0.f);
+                const bool zp = wave_sum_f32(rp) == 0.f, zt = wave_sum_f32(rt) == 0.f;
+                if (lane == 0) {
+                    mp_s[f] = zp ? 0ull : bp;
+                    mt_s[f] = zt ? 0ull : bt;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave's own LDS stores have landed
 
         // ---- location_sensitive_detection ----
         // per frame (lane = frame): the counts that do not depend on the matching
@@ -187,22 +157,32 @@ __global__ __launch_bounds__(256) void metrics_kernel(const MetricsP p) {
                 cnt[1] += n_p;
             }
         }
-        // per (frame, reference slot): is there a prediction of its class within the threshold?
-        for (int item = lane; item < nf * n; item += 64) {
+        // per (frame, reference slot): is there a prediction of its class within the threshold?  All twelve coordinate
+        // loads of an item are issued together (clamped addresses, results masked): one memory latency per item.
+        for (int base = 0; base < nf * n; base += 64) {
+            const int item = min(base + lane, nf * n - 1);
             const int f = item / n, j = item - f * n;
             const unsigned long long mp_f = mp_s[f];
-            if (!((mt_s[f] >> j) & 1ull) || mp_f == 0ull) continue;
             const int c = j / p.overlaps;
-            double t[3];
-            load_xyz(tgt_s + f * 4 * n + n, j, p.max_loc, t);
+            const bool act = base + lane < nf * n && ((mt_s[f] >> j) & 1ull) && mp_f != 0ull;
+            const float* lt = tgt + (size_t)f * 4 * n + n + (size_t)j * 3;
+            const float* lp = doa + (size_t)f * 3 * n + (size_t)c * p.overlaps * 3;
+            Xyz tq = {{0.f, 0.f, 0.f}}, qq[3] = {{{0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f}}};
+            if (act) {
+                tq = *reinterpret_cast<const Xyz*>(lt);
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    if (e < p.overlaps) qq[e] = *reinterpret_cast<const Xyz*>(lp + e * 3);
+            }
+            const float* tv = tq.v;
             bool match = false;
-            for (int e = 0; e < p.overlaps; ++e) {
-                const int k = c * p.overlaps + e;
-                if (!((mp_f >> k) & 1ull)) continue;
-                double q[3];
-                load_xyz(doa_s + f * 3 * n, k, p.max_loc, q);
-                const double dx = t[0] - q[0], dy = t[1] - q[1], dz = t[2] - q[2];
-                if (sqrt(dx * dx + dy * dy + dz * dz) < p.spatial_threshold) match = true;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const bool on = act && e < p.overlaps && ((mp_f >> (c * p.overlaps + e)) & 1ull);
+                const double dx = (double)(tv[0] * p.max_loc) - (double)(qq[e].v[0] * p.max_loc);
+                const double dy = (double)(tv[1] * p.max_loc) - (double)(qq[e].v[1] * p.max_loc);
+                const double dz = (double)(tv[2] * p.max_loc) - (double)(qq[e].v[2] * p.max_loc);
+                if (on && sqrt(dx * dx + dy * dy + dz * dz) < p.spatial_threshold) match = true;
             }
             if (match) {
                 cnt[0] += 1;
@@ -210,7 +190,6 @@ __global__ __launch_bounds__(256) void metrics_kernel(const MetricsP p) {
                 cnt[1] -= 1;
             }
         }
-
         // ---- DCASE21 segment metrics ----
         // step 1a (lane = (class, frame)): list the (reference slot, predicted slot) pairs that need a distance.  Only
         // ~1 % of the 9 * classes * frames candidates exist; computing them where they fall would make every lane
@@ -248,8 +227,8 @@ __global__ __launch_bounds__(256) void metrics_kernel(const MetricsP p) {
             const unsigned d = list_s[i];
             const int c = d >> 16, f = (d >> 8) & 255, e = (d >> 2) & 3, e2 = d & 3;
             double a[3], b[3];
-            load_xyz(tgt_s + f * 4 * n + n, c * p.overlaps + e, p.max_loc, a);
-            load_xyz(doa_s + f * 3 * n, c * p.overlaps + e2, p.max_loc, b);
+            load_xyz(tgt + (size_t)f * 4 * n + n, c * p.overlaps + e, p.max_loc, a);
+            load_xyz(doa + (size_t)f * 3 * n, c * p.overlaps + e2, p.max_loc, b);
             cost_s[((size_t)c * p.fpb + f) * 9 + e * 3 + e2] = angular_distance_deg(a, b);
         }
         __builtin_amdgcn_wave_barrier();
@@ -321,6 +300,7 @@ __global__ __launch_bounds__(256) void metrics_kernel(const MetricsP p) {
         if (lane < p.classes) {
             const int sh = lane * p.overlaps;
             int nb_gt = 0, nb_pred = 0;
+#pragma unroll 5
             for (int f = 0; f < nf; ++f) {
                 nb_gt = max(nb_gt, __popcll((mt_s[f] >> sh) & cls_mask));
                 nb_pred = max(nb_pred, __popcll((mp_s[f] >> sh) & cls_mask));
@@ -329,6 +309,7 @@ __global__ __launch_bounds__(256) void metrics_kernel(const MetricsP p) {
             if (nb_gt && nb_pred) {
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
                 int n0 = 0, n1 = 0, n2 = 0;
+#pragma unroll 5
                 for (int f = 0; f < nf; ++f) {
                     const double* src = match_s + ((size_t)lane * p.fpb + f) * 3;
                     const double d0 = src[0], d1 = src[1], d2 = src[2];
@@ -425,15 +406,14 @@ extern "C" int seld_metrics_accumulate(const float* sed, const float* doa, const
     p.counters = reinterpret_cast<long long*>(counters);
     p.total_de = total_de;
     const long long total = (long long)clips * p.blocks;
-    // per wave: fpb rows of 8n floats, 2 fpb masks, 9 classes fpb costs (f64), 9 classes fpb pair descriptors / 3 classes
-    // fpb matched distances (f64); 8n*fpb is even, so the u64 / f64 areas behind it are 8-byte aligned
-    const size_t slice = ((size_t)frames_per_block * 8 * classes * overlaps + 4 * (size_t)frames_per_block +
-                          27 * (size_t)classes * frames_per_block) * sizeof(float);
-    const int wpw = 1;                                   // waves per workgroup (29 KB of LDS at 14 x 3 x 10: 5 workgroups per CU)
+    // per wave: 2 fpb masks (u64), 9 classes fpb costs (f64), 9 classes fpb pair descriptors / 3 classes fpb matched
+    // distances (f64)
+    const size_t slice = (4 * (size_t)frames_per_block + 27 * (size_t)classes * frames_per_block) * sizeof(float);
+    const int wpw = 1;                                   // waves per workgroup (15 KB of LDS at 14 x 3 x 10: 10 workgroups per CU)
     const size_t smem = wpw * slice;
     if (smem > 64 * 1024) return SELD_EUNSUPPORTED;
     long long wgs = (total + wpw - 1) / wpw;
-    if (wgs > 2560) wgs = 2560;                          // 2 generations of resident waves; waves loop over their units
+    if (wgs > 4096) wgs = 4096;                          // 2 generations of resident waves; waves loop over their units
     hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)wgs), dim3(64 * wpw), smem, (hipStream_t)stream, p);
     return check_launch();
 }
