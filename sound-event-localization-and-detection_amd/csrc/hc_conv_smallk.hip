@@ -22,11 +22,24 @@ namespace seld {
 // per CU keeps its two waves per SIMD in lock-step.  SELD_SMALLK_NW=8 selects the latter (tuning aid).
 template <int NW> struct SkGeom { static constexpr int TP = NW * 16, NT = NW * 64; };
 
-template <int CT, int KH_T, int KW_T, int SK_NW>
-__global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP p, int NG, int NGP, long long ntiles) {
+// NG_T / NGP_T: k-group counts known at compile time (0 = take the run-time arguments).  With constants the two MFMA loops
+// unroll completely and the compiler hoists the LDS operand reads of later groups above the MFMAs of earlier ones; as
+// run-time loops every group started with an exposed LDS round trip (the MFMA pipe sat idle for a third of the loop).
+template <int CT, int KH_T, int KW_T, int SK_NW, int NG_T, int NGP_T>
+__global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP p, int NG_arg, int NGP_arg, long long ntiles) {
+    const int NG = NG_T ? NG_T : NG_arg;
+    const int NGP = NG_T ? NGP_T : NGP_arg;
     constexpr int BC = CT * 16;
     constexpr int SK_TP = SkGeom<SK_NW>::TP, SK_NT = SkGeom<SK_NW>::NT;
     constexpr bool DB = (SK_NW == 8);                    // double-buffered X image (4-wave variant: single buffer, two barriers)
+    // SPLIT (dual quaternion first layer, 4 waves): a wave owns 32 positions x (CT/4 primal + CT/4 dual) channel tiles instead
+    // of 16 positions x all CT tiles.  Same 12 accumulators and MFMA count, but (a) the two 16-position halves of a
+    // channel are stored back to back by ONE wave, completing 128-byte lines (with 16 positions per wave every store
+    // instruction left sixteen 64-byte half lines for another wave to finish: the write stream ran at 2.3 TB/s), and
+    // (b) 8 instead of 13 LDS operand reads per k-group.  Primal and dual tiles are dealt evenly, so the waves stay
+    // balanced although primal channels stop after half the groups.
+    constexpr bool SPLIT = NG_T && (NGP_T * 2 == NG_T) && SK_NW == 4 && (CT % 4 == 0);
+    constexpr int QT = CT / 4;                           // primal (and dual) channel tiles per wave in SPLIT mode
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ws = smem;                                    // [NG][BC][4]
     float* Xs = smem + (size_t)NG * BC * 4;              // [2][NG][SK_TP][4]
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
     // im2col items of one tile: (g, pos), pos = tid & 127 for every item of this thread, g = (tid >> 7) + 4*i
     const int xpos = tid & (SK_TP - 1);
     const int xg0 = __builtin_amdgcn_readfirstlane(tid / SK_TP);
-    constexpr int XI_MAX = 10;                           // NG <= 40
+    constexpr int XI_MAX = NG_T ? (NG_T + 3) / 4 : 10;   // NG <= 40
     const int xi_n = (NG - xg0 + 3) / 4;                 // items of this thread
     float xr[XI_MAX][4];
 
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
         const unsigned img_b = img * (unsigned)(p.Csrc * p.srcS) * 4u;
 #pragma unroll
         for (int i = 0; i < XI_MAX; ++i) {
-            if (i < xi_n) {
+            if (NG_T || i < xi_n) {                      // compile-time group count: no branch, surplus groups load zeros
                 const int g = xg0 + 4 * i;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -99,7 +112,7 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
                     const int kidx = kkc - chan * KK;
                     const int kh = kidx / KW, kw = kidx - kh * KW;
                     const int ih = base_h + kh * p.KDh, iw = base_w + kw * p.KDw;
-                    const bool ok = pvalid && kk < p.Ktot && (unsigned)ih < (unsigned)p.srcH && (unsigned)iw < (unsigned)p.srcW;
+                    const bool ok = pvalid && kk < p.Ktot && g < NG && (unsigned)ih < (unsigned)p.srcH && (unsigned)iw < (unsigned)p.srcW;
                     const unsigned off = ok ? img_b + (unsigned)((chan * p.srcS + ih * p.srcW + iw) * 4) : 0xFFFFFFFFu;
                     xr[i][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
                 }
@@ -119,7 +132,9 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
 #pragma unroll
     for (int j = 0; j < CT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 
-    const int dbg = p.wt;      // experiment switches (wt is unused by the forward): 1 = no stores, 2 = no gathers
+    // experiment switches (wt is unused by the forward): 1 = no stores, 2 = no gathers, 4 = store before the LDS refill;
+    // the compile-time-shaped instantiation keeps only bit 4
+    const int dbg = NG_T ? (p.wt & 4) : p.wt;
     long long tile = blockIdx.x;
     if (tile < ntiles) { gather(tile); scatter(0); }
     __syncthreads();
@@ -127,15 +142,40 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
     int buf = 0;
     for (; tile < ntiles; tile += gridDim.x) {
         const long long next = tile + gridDim.x;
-        if (next < ntiles && !(dbg & 2)) gather(next);
+        if (NG_T) gather(next < ntiles ? next : tile);          // unconditional: keeps the loop body one block
+        else if (next < ntiles && !(dbg & 2)) gather(next);
 
-        floatx4 acc[CT];
+        floatx4 acc[CT];                                   // SPLIT: acc[sub * 2 QT + t], t < QT primal, t >= QT dual
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT) {
+            const int half = wave & 1, cgp = wave >> 1;
+            const float* xb = Xs + (size_t)buf * NG * SK_TP * 4 + (size_t)(half * 32 + fr) * 4 + fk;
+            const float* wp = Ws + (size_t)(cgp * QT * 16 + fr) * 4 + fk;                      // primal tiles of this wave
+            const float* wd = Ws + (size_t)((CT / 2 + cgp * QT) * 16 + fr) * 4 + fk;             // dual tiles
+#pragma unroll
+            for (int g = 0; g < NG_T; ++g) {
+                const float a0 = xb[(size_t)g * SK_TP * 4], a1 = xb[(size_t)g * SK_TP * 4 + 64];
+                if (g < NGP_T) {
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        const float b = wp[((size_t)g * BC + t * 16) * 4];
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[t], 0, 0, 0);
+                        acc[2 * QT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[2 * QT + t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const float b = wd[((size_t)g * BC + t * 16) * 4];
+                    acc[QT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[QT + t], 0, 0, 0);
+                    acc[3 * QT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[3 * QT + t], 0, 0, 0);
+                }
+            }
+        } else {
         const float* xb = Xs + (size_t)buf * NG * SK_TP * 4 + (size_t)(wave * 16 + fr) * 4 + fk;
         const float* wb = Ws + (size_t)fr * 4 + fk;
-        // groups every channel tile needs (unrolled x3 so that the next groups' LDS reads issue under the MFMAs)
-#pragma unroll 3
+        // groups every channel tile needs
+#pragma unroll
         for (int g = 0; g < NGP; ++g) {
             const float a = xb[(size_t)g * SK_TP * 4];
 #pragma unroll
@@ -143,30 +183,66 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[((size_t)g * BC + j * 16) * 4], acc[j], 0, 0, 0);
         }
         // groups in the structurally-zero K half of the primal channels: upper half of the tiles only
-#pragma unroll 3
+#pragma unroll
         for (int g = NGP; g < NG; ++g) {
             const float a = xb[(size_t)g * SK_TP * 4];
 #pragma unroll
             for (int j = CT / 2; j < CT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[((size_t)g * BC + j * 16) * 4], acc[j], 0, 0, 0);
         }
-
-        // store: lane owns channel j*16+fr, positions tile*128 + wave*16 + fk*4 .. +3
-        const unsigned pos = (unsigned)(tile * SK_TP) + wave * 16 + fk * 4;
-        if (pos < (unsigned)p.Ptot) {
-            const unsigned img = pos / (unsigned)p.dstS;
-            const unsigned rem = pos - img * (unsigned)p.dstS;
-            float* drow = p.dst + (size_t)img * p.Cdst * p.dstS + rem;
-#pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                const int ch = j * 16 + fr;
-                const float bvv = p.bias ? p.bias[ch] : 0.f;
-                const float4 o = make_float4(acc[j][0] + bvv, acc[j][1] + bvv, acc[j][2] + bvv, acc[j][3] + bvv);
-                if (!(dbg & 1)) *reinterpret_cast<float4*>(drow + (size_t)ch * p.dstS) = o;
-                s1[j] += (o.x + o.y) + (o.z + o.w);
-                s2[j] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-            }
         }
+
+        auto store_tile = [&]() __attribute__((always_inline)) {
+            if constexpr (SPLIT) {
+                // lane owns channel TJ*16+fr, positions tile*64 + half*32 + sub*16 + fk*4 .. +3 for sub = 0, 1
+                const int half = wave & 1, cgp = wave >> 1;
+                const unsigned pos = (unsigned)(tile * SK_TP) + half * 32 + fk * 4;
+                const unsigned img = pos / (unsigned)p.dstS;
+                const unsigned rem = pos - img * (unsigned)p.dstS;
+                float* drow = p.dst + (size_t)img * p.Cdst * p.dstS + rem;
+                const bool ok0 = pos < (unsigned)p.Ptot, ok1 = pos + 16 < (unsigned)p.Ptot;      // dstS % 64 == 0: same image
+#pragma unroll
+                for (int t = 0; t < 2 * QT; ++t) {
+                    const int ch = (t < QT ? cgp * QT + t : CT / 2 + cgp * QT + (t - QT)) * 16 + fr;
+                    const float bvv = p.bias ? p.bias[ch] : 0.f;
+                    const floatx4 c0 = acc[t], c1 = acc[2 * QT + t];
+                    const float4 o0 = make_float4(c0[0] + bvv, c0[1] + bvv, c0[2] + bvv, c0[3] + bvv);
+                    const float4 o1 = make_float4(c1[0] + bvv, c1[1] + bvv, c1[2] + bvv, c1[3] + bvv);
+                    if (ok0) {
+                        if (!(dbg & 1)) *reinterpret_cast<float4*>(drow + (size_t)ch * p.dstS) = o0;
+                        s1[t] += (o0.x + o0.y) + (o0.z + o0.w);
+                        s2[t] += (o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w);
+                    }
+                    if (ok1) {
+                        if (!(dbg & 1)) *reinterpret_cast<float4*>(drow + (size_t)ch * p.dstS + 16) = o1;
+                        s1[t] += (o1.x + o1.y) + (o1.z + o1.w);
+                        s2[t] += (o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w);
+                    }
+                }
+                return;
+            }
+            // store: lane owns channel j*16+fr, positions tile*128 + wave*16 + fk*4 .. +3
+            const unsigned pos = (unsigned)(tile * SK_TP) + wave * 16 + fk * 4;
+            if (pos < (unsigned)p.Ptot) {
+                const unsigned img = pos / (unsigned)p.dstS;
+                const unsigned rem = pos - img * (unsigned)p.dstS;
+                float* drow = p.dst + (size_t)img * p.Cdst * p.dstS + rem;
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int ch = j * 16 + fr;
+                    const float bvv = p.bias ? p.bias[ch] : 0.f;
+                    const float4 o = make_float4(acc[j][0] + bvv, acc[j][1] + bvv, acc[j][2] + bvv, acc[j][3] + bvv);
+                    if (!(dbg & 1)) *reinterpret_cast<float4*>(drow + (size_t)ch * p.dstS) = o;
+                    s1[j] += (o.x + o.y) + (o.z + o.w);
+                    s2[j] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                }
+            }
+        };
+        if (dbg & 4) store_tile();
+        // The next tile's image is dropped into LDS BEFORE this tile's results are stored: on gfx9 loads and stores share
+        // vmcnt and complete out of order with respect to each other, so a wait for the gather behind the 12 stores is a
+        // wait for the stores' write acknowledgements (35 % of the wave's time, measured).  This way the stores of tile t
+        // have the whole MFMA phase of tile t+1 to drain.
         if (DB) {
             if (next < ntiles) scatter(buf ^ 1);
             __syncthreads();
@@ -176,11 +252,29 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
             if (next < ntiles) scatter(0);
             __syncthreads();
         }
+
+        if (!(dbg & 4)) store_tile();
     }
 
     if (p.epilogue & SELD_EPI_STATS) {
         // lanes fr, fr+16, fr+32, fr+48 hold the same channel; 8 waves hold different positions
         float* red = Xs;                                   // free now: [SK_NW][BC][2]
+        if constexpr (SPLIT) {
+            for (int t = tid; t < SK_NW * BC * 2; t += SK_NT) red[t] = 0.f;       // a wave fills its own tiles only
+            __syncthreads();
+            const int cgp = wave >> 1;
+#pragma unroll
+            for (int t = 0; t < 2 * QT; ++t) {
+                const int ch = (t < QT ? cgp * QT + t : CT / 2 + cgp * QT + (t - QT)) * 16 + fr;
+                float a = s1[t], b = s2[t];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                if (fk == 0) {
+                    red[(wave * BC + ch) * 2 + 0] = a;
+                    red[(wave * BC + ch) * 2 + 1] = b;
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
             float a = s1[j], b = s2[j];
@@ -190,6 +284,7 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
                 red[(wave * BC + j * 16 + fr) * 2 + 0] = a;
                 red[(wave * BC + j * 16 + fr) * 2 + 1] = b;
             }
+        }
         }
         __syncthreads();
         float* rep = p.stats + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
@@ -210,17 +305,18 @@ static int launch_smallk(const ConvP& p, int NG, int NGP, hipStream_t st) {
     const size_t smem = ((size_t)NG * CT * 16 * 4 + (size_t)(NW == 8 ? 2 : 1) * NG * TP * 4) * sizeof(float);
     const long long want = 256 * (8 / NW);                 // one 8-wave or two 4-wave workgroups per CU
     const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
-#define SELD_SK(KH_, KW_)                                                                                          \
+#define SELD_SK(KH_, KW_, NG_, NGP_)                                                                               \
     do {                                                                                                           \
-        auto kern = hc_conv_smallk_kernel<CT, KH_, KW_, NW>;                                                       \
+        auto kern = hc_conv_smallk_kernel<CT, KH_, KW_, NW, NG_, NGP_>;                                            \
         if (smem > 64 * 1024 &&                                                                                    \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return SELD_ELAUNCH;                                                                                   \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p, NG, NGP, ntiles);                              \
     } while (0)
-    if (p.KH == 1 && p.KW == 3) SELD_SK(1, 3);
-    else if (p.KH == 3 && p.KW == 3) SELD_SK(3, 3);
-    else SELD_SK(0, 0);
+    if (p.KH == 1 && p.KW == 3) SELD_SK(1, 3, 0, 0);
+    else if (p.KH == 3 && p.KW == 3 && NG == 18 && NGP == 9 && p.dstS % 64 == 0) SELD_SK(3, 3, 18, 9);   // the 8-channel first layer
+    else if (p.KH == 3 && p.KW == 3) SELD_SK(3, 3, 0, 0);
+    else SELD_SK(0, 0, 0, 0);
 #undef SELD_SK
     return check_launch();
 }
