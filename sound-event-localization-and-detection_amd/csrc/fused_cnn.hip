@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
 
 // Same for pooling along H only (pw == 1, the SELD CNN stages) and W a multiple of 4: a thread owns 4 adjacent
 // columns, every access is 16 bytes.
+// PH: window height known at compile time (0 = run-time g.ph): all PH row loads are issued before the first compare.
+template <int PH>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_v4_kernel(const float* __restrict__ y, PoolGeom g,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd,
@@ -67,8 +69,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_v4_kernel(const float* _
     const float* base = y + ((size_t)nc * g.H + (size_t)oh * g.ph) * g.W + ow;
     float best[4] = {0.f, 0.f, 0.f, 0.f};
     int bi[4] = {0, 0, 0, 0};
-    for (int r = 0; r < g.ph; ++r) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * g.W);
+    auto take = [&](const float4 v, int r) __attribute__((always_inline)) {
         const float zz[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -76,6 +77,15 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_v4_kernel(const float* _
             z = z > 0.f ? z : 0.f;
             if (r == 0 || z > best[e] || z != z) { best[e] = z; bi[e] = r; }
         }
+    };
+    if constexpr (PH > 0) {
+        float4 v[PH];
+#pragma unroll
+        for (int r = 0; r < PH; ++r) v[r] = *reinterpret_cast<const float4*>(base + (size_t)r * g.W);
+#pragma unroll
+        for (int r = 0; r < PH; ++r) take(v[r], r);
+    } else {
+        for (int r = 0; r < g.ph; ++r) take(*reinterpret_cast<const float4*>(base + (size_t)r * g.W), r);
     }
     *reinterpret_cast<float4*>(pooled + i) = make_float4(best[0], best[1], best[2], best[3]);
     *reinterpret_cast<uchar4*>(idx + i) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
@@ -251,10 +261,18 @@ extern "C" int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32
     int rc = mk_geom(g, N, C, H, W, ph, pw);
     if (rc) return rc;
     if (!y || !mean || !invstd || !gamma || !beta || !pooled || !idx) return SELD_EINVAL;
-    if (pw == 1 && W % 4 == 0)
-        hipLaunchKernelGGL(bn_relu_pool_fwd_v4_kernel, dim3((g.OW / 4 + 127) / 128, g.OH, (unsigned)g.NC), dim3(128), 0,
-                           (hipStream_t)stream, y, g, mean, invstd, gamma, beta, pooled, idx);
-    else
+    if (pw == 1 && W % 4 == 0) {
+        const dim3 grid((g.OW / 4 + 127) / 128, g.OH, (unsigned)g.NC);
+        if (ph == 8)
+            hipLaunchKernelGGL(bn_relu_pool_fwd_v4_kernel<8>, grid, dim3(128), 0, (hipStream_t)stream, y, g, mean, invstd, gamma,
+                               beta, pooled, idx);
+        else if (ph == 2)
+            hipLaunchKernelGGL(bn_relu_pool_fwd_v4_kernel<2>, grid, dim3(128), 0, (hipStream_t)stream, y, g, mean, invstd, gamma,
+                               beta, pooled, idx);
+        else
+            hipLaunchKernelGGL(bn_relu_pool_fwd_v4_kernel<0>, grid, dim3(128), 0, (hipStream_t)stream, y, g, mean, invstd, gamma,
+                               beta, pooled, idx);
+    } else
         hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((g.OW + 255) / 256, g.OH, (unsigned)g.NC), dim3(256), 0, (hipStream_t)stream, y, g,
                            mean, invstd, gamma, beta, pooled, idx);
     return check_launch();
