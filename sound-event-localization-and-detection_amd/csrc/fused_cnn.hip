@@ -110,15 +110,15 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const floa
     long long end = beg + 8192;
     if (end > M) end = M;
     float v0 = 0.f, v1 = 0.f;
-    for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
-        const long long n = i / S;
-        const size_t off = ((size_t)n * C + c) * S + (size_t)(i - n * S);
-        const float z = pooled[off];
+    // One 64-bit division per workgroup, 32-bit arithmetic per element; a thread owns 4 consecutive elements (S % 4 == 0:
+    // they lie in one sample) and both 16-byte loads are issued before either is used.
+    const long long n0 = beg / S;
+    const unsigned r_beg = (unsigned)(beg - n0 * S);
+    const unsigned count = (unsigned)(end - beg);
+    auto one = [&](float z, float d, long long n, unsigned s_, size_t off) __attribute__((always_inline)) {
         if (z > 0.f) {
-            const float d = dpooled[off];
             float xh = (z - be) * inv_g;
             if (degenerate) {
-                const int s_ = (int)(i - n * S);
                 const int oh = s_ / g.OW, ow = s_ - oh * g.OW;
                 const int am = idx[off];
                 const int r = am / g.pw, q = am - r * g.pw;
@@ -126,6 +126,30 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const floa
             }
             v0 += d * xh;
             v1 += d;
+        }
+    };
+    if ((S & 3) == 0) {
+        for (unsigned k = threadIdx.x * 4; k < count; k += blockDim.x * 4) {
+            const unsigned local = r_beg + k;
+            const unsigned dn = local / (unsigned)S;
+            const unsigned s_ = local - dn * (unsigned)S;
+            const long long n = n0 + dn;
+            const size_t off = ((size_t)n * C + c) * S + s_;
+            const float4 z4 = *reinterpret_cast<const float4*>(pooled + off);
+            const float4 d4 = *reinterpret_cast<const float4*>(dpooled + off);
+            one(z4.x, d4.x, n, s_, off);
+            one(z4.y, d4.y, n, s_ + 1, off + 1);
+            one(z4.z, d4.z, n, s_ + 2, off + 2);
+            one(z4.w, d4.w, n, s_ + 3, off + 3);
+        }
+    } else {
+        for (unsigned k = threadIdx.x; k < count; k += blockDim.x) {
+            const unsigned local = r_beg + k;
+            const unsigned dn = local / (unsigned)S;
+            const unsigned s_ = local - dn * (unsigned)S;
+            const long long n = n0 + dn;
+            const size_t off = ((size_t)n * C + c) * S + s_;
+            one(pooled[off], dpooled[off], n, s_, off);
         }
     }
     __shared__ float r0[4], r1[4];
