@@ -20,6 +20,14 @@ namespace seld {
 // Waves per workgroup.  4-wave workgroups, two per CU (each with its own copy of the weights in LDS), run out of
 // phase with each other, so one workgroup's stores / gathers hide under the other's MFMAs; an 8-wave workgroup
 // per CU keeps its two waves per SIMD in lock-step.  SELD_SMALLK_NW=8 selects the latter (tuning aid).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over ALL address spaces: on
+// gfx9 it waits vmcnt(0), i.e. for the write acknowledgement of every global store the wave has in flight -- in a loop
+// that stores 12 KB per wave per tile that wait was a third of the kernel.  The image in LDS is the only data the waves
+// exchange here; results go to memory nobody in the workgroup reads.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NW> struct SkGeom { static constexpr int TP = NW * 16, NT = NW * 64; };
 
 // NG_T / NGP_T: k-group counts known at compile time (0 = take the run-time arguments).  With constants the two MFMA loops
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
 #pragma unroll
     for (int j = 0; j < CT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 
-    // experiment switches (wt is unused by the forward): 1 = no stores, 2 = no gathers, 4 = store before the LDS refill;
+    // experiment switches (wt is unused by the forward): 1 = no stores, 2 = no gathers, 4 = store after the LDS refill;
     // the compile-time-shaped instantiation keeps only bit 4
     const int dbg = NG_T ? (p.wt & 4) : p.wt;
     long long tile = blockIdx.x;
@@ -238,22 +246,23 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
                 }
             }
         };
-        if (dbg & 4) store_tile();
-        // The next tile's image is dropped into LDS BEFORE this tile's results are stored: on gfx9 loads and stores share
-        // vmcnt and complete out of order with respect to each other, so a wait for the gather behind the 12 stores is a
-        // wait for the stores' write acknowledgements (35 % of the wave's time, measured).  This way the stores of tile t
-        // have the whole MFMA phase of tile t+1 to drain.
+        if (!(dbg & 4)) store_tile();
+        // (SELD_SMALLK_DBG bit 4 stores AFTER the LDS refill instead: 656 vs 648 us.)  What keeps stores, gathers and MFMAs
+        // from overlapping is visible in the ISA: the first LDS operand reads of the next tile reuse the VGPRs that held this
+        // tile's store addresses / data, and the compiler guards that reuse with s_waitcnt vmcnt(..) -- the next tile's MFMAs
+        // start only when this tile's stores are acknowledged.  Stores straight from a second, alternating accumulator set
+        // with SGPR-base addressing would remove the reuse; not done yet.
         if (DB) {
             if (next < ntiles) scatter(buf ^ 1);
-            __syncthreads();
+            lds_barrier();
             buf ^= 1;
         } else {
-            __syncthreads();                               // everyone is done reading the image
+            lds_barrier();                               // everyone is done reading the image
             if (next < ntiles) scatter(0);
-            __syncthreads();
+            lds_barrier();
         }
 
-        if (!(dbg & 4)) store_tile();
+        if (dbg & 4) store_tile();
     }
 
     if (p.epilogue & SELD_EPI_STATS) {
