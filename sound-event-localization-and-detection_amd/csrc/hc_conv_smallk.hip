@@ -14,6 +14,7 @@
 //   * each lane stores 4 consecutive positions of a channel (16-byte stores); BatchNorm statistics are kept in
 //     registers across tiles and leave the workgroup as ONE set of atomics.
 #include "hc_common.h"
+#include <type_traits>
 
 namespace seld {
 
@@ -127,6 +128,45 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
             }
         }
     };
+    // SPLIT gather: the k-groups of a thread depend only on its wave (g = wave + 4 i), so with the wave index as a
+    // compile-time constant every (channel, kh, kw) of its 20 loads is a constant; a 64-position tile lies in one output
+    // row (dstW % 64 == 0), so image / row arithmetic and the row validity are scalar, the column validity is three lane
+    // masks per tile.  ~100 instead of ~360 instructions per tile (the loop issued 6.6 non-MFMA instructions per MFMA).
+    auto gather_fast = [&](long long tile, auto wc) __attribute__((always_inline)) {
+        constexpr int W = decltype(wc)::value;
+        const unsigned pos0 = __builtin_amdgcn_readfirstlane((unsigned)(tile * SK_TP));
+        const unsigned img = pos0 / (unsigned)p.dstS;
+        const unsigned rem = pos0 - img * (unsigned)p.dstS;
+        const unsigned oh = rem / (unsigned)p.dstW;
+        const unsigned ow0 = rem - oh * (unsigned)p.dstW;
+        const int base_h = (int)oh + p.OFFh;
+        const int iw0 = (int)ow0 + p.OFFw + xpos;
+        const bool c0 = (unsigned)iw0 < (unsigned)p.srcW, c1 = (unsigned)(iw0 + 1) < (unsigned)p.srcW,
+                   c2 = (unsigned)(iw0 + 2) < (unsigned)p.srcW;
+        const bool r0 = (unsigned)base_h < (unsigned)p.srcH, r1 = (unsigned)(base_h + 1) < (unsigned)p.srcH,
+                   r2 = (unsigned)(base_h + 2) < (unsigned)p.srcH;
+        const unsigned vbase = (img * (unsigned)(p.Csrc * p.srcS) + (unsigned)(base_h * p.srcW + iw0)) * 4u;
+#pragma unroll
+        for (int i = 0; i < XI_MAX; ++i) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                constexpr int dummy = 0;
+                const int g = W + 4 * i, kk = g * 4 + s;           // constants after unrolling
+                const int chan = kk / 9, kh = (kk % 9) / 3, kw = kk % 3;
+                const bool live = g < NG_T && kk < NG_T * 4 && kk < 9 * 8;
+                const bool ok = live && (kh == 0 ? r0 : kh == 1 ? r1 : r2) && (kw == 0 ? c0 : kw == 1 ? c1 : c2);
+                const unsigned off = ok ? vbase + (unsigned)((chan * p.srcS + kh * p.srcW + kw) * 4) : 0xFFFFFFFFu;
+                xr[i][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+                (void)dummy;
+            }
+        }
+    };
+    auto gather_split = [&](long long tile) __attribute__((always_inline)) {
+        if (wave == 0) gather_fast(tile, std::integral_constant<int, 0>{});
+        else if (wave == 1) gather_fast(tile, std::integral_constant<int, 1>{});
+        else if (wave == 2) gather_fast(tile, std::integral_constant<int, 2>{});
+        else gather_fast(tile, std::integral_constant<int, 3>{});
+    };
     auto scatter = [&](int buf) __attribute__((always_inline)) {
         float* dst = Xs + (size_t)buf * NG * SK_TP * 4;
 #pragma unroll
@@ -139,23 +179,37 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
     float s1[CT], s2[CT];
 #pragma unroll
     for (int j = 0; j < CT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    float bias_t[CT];                                      // SPLIT: bias of the lane's channel in each of its 2 QT tiles
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int cg = wave >> 1;
+        const int ch = ((t % (2 * QT)) < QT ? cg * QT + (t % (2 * QT)) : CT / 2 + cg * QT + ((t % (2 * QT)) - QT)) * 16 + fr;
+        bias_t[t] = (SPLIT && p.bias) ? p.bias[ch] : 0.f;
+    }
 
     // experiment switches (wt is unused by the forward): 1 = no stores, 2 = no gathers, 4 = store after the LDS refill;
     // the compile-time-shaped instantiation keeps only bit 4
     const int dbg = NG_T ? (p.wt & 4) : p.wt;
     long long tile = blockIdx.x;
-    if (tile < ntiles) { gather(tile); scatter(0); }
+    if (tile < ntiles) {
+        if constexpr (SPLIT) gather_split(tile); else gather(tile);
+        scatter(0);
+    }
     __syncthreads();
 
     int buf = 0;
     for (; tile < ntiles; tile += gridDim.x) {
         const long long next = tile + gridDim.x;
-        if (NG_T) gather(next < ntiles ? next : tile);          // unconditional: keeps the loop body one block
+        if constexpr (SPLIT) gather_split(next < ntiles ? next : tile);
+        else if (NG_T) gather(next < ntiles ? next : tile);          // unconditional: keeps the loop body one block
         else if (next < ntiles && !(dbg & 2)) gather(next);
 
         floatx4 acc[CT];                                   // SPLIT: acc[sub * 2 QT + t], t < QT primal, t >= QT dual
 #pragma unroll
-        for (int j = 0; j < CT; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < CT; ++j) {
+            const float b0 = SPLIT ? bias_t[j % (2 * QT)] : 0.f;      // SPLIT: the bias rides in the accumulator
+            acc[j] = (floatx4){b0, b0, b0, b0};
+        }
         if constexpr (SPLIT) {
             const int half = wave & 1, cgp = wave >> 1;
             const float* xb = Xs + (size_t)buf * NG * SK_TP * 4 + (size_t)(half * 32 + fr) * 4 + fk;
@@ -212,10 +266,9 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
 #pragma unroll
                 for (int t = 0; t < 2 * QT; ++t) {
                     const int ch = (t < QT ? cgp * QT + t : CT / 2 + cgp * QT + (t - QT)) * 16 + fr;
-                    const float bvv = p.bias ? p.bias[ch] : 0.f;
                     const floatx4 c0 = acc[t], c1 = acc[2 * QT + t];
-                    const float4 o0 = make_float4(c0[0] + bvv, c0[1] + bvv, c0[2] + bvv, c0[3] + bvv);
-                    const float4 o1 = make_float4(c1[0] + bvv, c1[1] + bvv, c1[2] + bvv, c1[3] + bvv);
+                    const float4 o0 = make_float4(c0[0], c0[1], c0[2], c0[3]);
+                    const float4 o1 = make_float4(c1[0], c1[1], c1[2], c1[3]);
                     if (ok0) {
                         if (!(dbg & 1)) *reinterpret_cast<float4*>(drow + (size_t)ch * p.dstS) = o0;
                         s1[t] += (o0.x + o0.y) + (o0.z + o0.w);
@@ -323,7 +376,8 @@ static int launch_smallk(const ConvP& p, int NG, int NGP, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p, NG, NGP, ntiles);                              \
     } while (0)
     if (p.KH == 1 && p.KW == 3) SELD_SK(1, 3, 0, 0);
-    else if (p.KH == 3 && p.KW == 3 && NG == 18 && NGP == 9 && p.dstS % 64 == 0) SELD_SK(3, 3, 18, 9);   // the 8-channel first layer
+    else if (p.KH == 3 && p.KW == 3 && NG == 18 && NGP == 9 && p.Ktot == 72 && p.dstS % 64 == 0 && p.dstW % 64 == 0 &&
+             p.Ptot % 64 == 0 && p.KDh == 1 && p.KDw == 1) SELD_SK(3, 3, 18, 9);   // the 8-channel first layer
     else if (p.KH == 3 && p.KW == 3) SELD_SK(3, 3, 0, 0);
     else SELD_SK(0, 0, 0, 0);
 #undef SELD_SK

@@ -282,3 +282,31 @@ def test_full_size_adjoint_and_linearity(name, shape, cout, k, pad, dil):
         y2 = H.hyper_conv(x2, wd, None, 1, pad, dil)
         err = float((y12 - (0.75 * y.detach() - 1.5 * y2)).abs().max())
         assert err < 1e-4 * float(y12.abs().max()), err
+
+
+def test_first_layer_kernel_matches_generic_kernel_and_oracle(monkeypatch):
+    """The persistent short-reduction kernel in its first-layer shape (8 -> 192 channels, 3x3, 64-position tiles in one
+    output row, bias folded into the accumulators, BatchNorm statistics in the epilogue) against the generic kernel on
+    the same full-size input (bit-level agreement is not expected: different summation order) and against the oracle on
+    one sample."""
+    import seld_amd
+    H, L = seld_amd.hip_ops, seld_amd._lib
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 8, 128, 512, generator=g)
+    ws = [torch.randn(24, 1, 3, 3, generator=g) * 0.2 for _ in range(8)]
+    bias = torch.randn(192, generator=g)
+    xd, wd, bd = x.to(DEV), [w.to(DEV) for w in ws], bias.to(DEV)
+    desc = H.make_conv_desc(tuple(x.shape), 192, 8, (3, 3), 1, 1, 1)
+    stats = H.new_stats(192, torch.device(DEV))
+    y = H.conv_fwd(desc, xd, wd, bias=bd, epilogue=L.SELD_EPI_STATS, stats=stats)
+    monkeypatch.setenv("SELD_CONV_NO_SMALLK", "1")
+    stats_ref = H.new_stats(192, torch.device(DEV))
+    y_ref = H.conv_fwd(desc, xd, wd, bias=bd, epilogue=L.SELD_EPI_STATS, stats=stats_ref)
+    monkeypatch.delenv("SELD_CONV_NO_SMALLK")
+    scale = float(y_ref.abs().max())
+    assert float((y - y_ref).abs().max()) <= 1e-5 * scale
+    s, sr = stats.view(-1, 2, 192).sum(0), stats_ref.view(-1, 2, 192).sum(0)
+    assert torch.allclose(s, sr, rtol=1e-4, atol=1e-2)
+    ref = O.dual_quaternion_conv(x[:1].double(), *[w.double() for w in ws], bias.double(), 1, 1, 1, 1)
+    assert float((y[:1].cpu().double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
