@@ -35,23 +35,28 @@ template <int NW> struct SkGeom { static constexpr int TP = NW * 16, NT = NW * 6
 // unroll completely and the compiler hoists the LDS operand reads of later groups above the MFMAs of earlier ones; as
 // run-time loops every group started with an exposed LDS round trip (the MFMA pipe sat idle for a third of the loop).
 template <int CT, int KH_T, int KW_T, int SK_NW, int NG_T, int NGP_T>
-__global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP p, int NG_arg, int NGP_arg, long long ntiles) {
+__global__ __launch_bounds__(SK_NW * 64, (SK_NW == 8 && NG_T) ? 4 : 1) void hc_conv_smallk_kernel(const ConvP p, int NG_arg, int NGP_arg, long long ntiles) {
     const int NG = NG_T ? NG_T : NG_arg;
     const int NGP = NG_T ? NGP_T : NGP_arg;
     constexpr int BC = CT * 16;
     constexpr int SK_TP = SkGeom<SK_NW>::TP, SK_NT = SkGeom<SK_NW>::NT;
-    constexpr bool DB = (SK_NW == 8);                    // double-buffered X image (4-wave variant: single buffer, two barriers)
     // SPLIT (dual quaternion first layer, 4 waves): a wave owns 32 positions x (CT/4 primal + CT/4 dual) channel tiles instead
     // of 16 positions x all CT tiles.  Same 12 accumulators and MFMA count, but (a) the two 16-position halves of a
     // channel are stored back to back by ONE wave, completing 128-byte lines (with 16 positions per wave every store
     // instruction left sixteen 64-byte half lines for another wave to finish: the write stream ran at 2.3 TB/s), and
     // (b) 8 instead of 13 LDS operand reads per k-group.  Primal and dual tiles are dealt evenly, so the waves stay
     // balanced although primal channels stop after half the groups.
-    constexpr bool SPLIT = NG_T && (NGP_T * 2 == NG_T) && SK_NW == 4 && (CT % 4 == 0);
+    constexpr bool SPLIT = NG_T && (NGP_T * 2 == NG_T) && (SK_NW == 4 || SK_NW == 8) && (CT % 4 == 0);
+    constexpr bool DB = (SK_NW == 8) && !SPLIT;          // double-buffered X image (else single buffer, two barriers)
+    // SPLIT keeps the structurally-zero quadrant out of the weight image (groups >= NGP hold the dual channels only): 41
+    // instead of 55 KB.  With 8 waves sharing it and a 128-position image that is 78 KB per workgroup: two per CU, four waves
+    // per SIMD.
+    constexpr int PQ = SK_NW / 2;                        // 32-position quarters (halves) of a tile, one per wave pair
     constexpr int QT = CT / 4;                           // primal (and dual) channel tiles per wave in SPLIT mode
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ws = smem;                                    // [NG][BC][4]
-    float* Xs = smem + (size_t)NG * BC * 4;              // [2][NG][SK_TP][4]
+    const int ws_groups = SPLIT ? NGP * BC + (NG - NGP) * (BC / 2) : NG * BC;     // 4-float weight groups in LDS
+    float* Ws = smem;                                    // [NG][BC][4]  (SPLIT: [NGP][BC][4] then [NG-NGP][BC/2][4])
+    float* Xs = smem + (size_t)ws_groups * 4;            // [2][NG][SK_TP][4]
     __shared__ const float* wptr_s[8];
 
     const int tid = threadIdx.x;
@@ -87,7 +92,13 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
             }
             v[s] = x;
         }
-        *reinterpret_cast<float4*>(&Ws[(size_t)idx * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (SPLIT) {
+            if (g >= NGP && ch < BC / 2) continue;        // zero quadrant: not stored
+            const int slot = g < NGP ? idx : NGP * BC + (g - NGP) * (BC / 2) + (ch - BC / 2);
+            *reinterpret_cast<float4*>(&Ws[(size_t)slot * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            *reinterpret_cast<float4*>(&Ws[(size_t)idx * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -162,9 +173,9 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
         }
     };
     auto gather_split = [&](long long tile) __attribute__((always_inline)) {
-        if (wave == 0) gather_fast(tile, std::integral_constant<int, 0>{});
-        else if (wave == 1) gather_fast(tile, std::integral_constant<int, 1>{});
-        else if (wave == 2) gather_fast(tile, std::integral_constant<int, 2>{});
+        if (xg0 == 0) gather_fast(tile, std::integral_constant<int, 0>{});
+        else if (xg0 == 1) gather_fast(tile, std::integral_constant<int, 1>{});
+        else if (xg0 == 2) gather_fast(tile, std::integral_constant<int, 2>{});
         else gather_fast(tile, std::integral_constant<int, 3>{});
     };
     auto scatter = [&](int buf) __attribute__((always_inline)) {
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
     float bias_t[CT];                                      // SPLIT: bias of the lane's channel in each of its 2 QT tiles
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
-        const int cg = wave >> 1;
+        const int cg = wave / PQ;
         const int ch = ((t % (2 * QT)) < QT ? cg * QT + (t % (2 * QT)) : CT / 2 + cg * QT + ((t % (2 * QT)) - QT)) * 16 + fr;
         bias_t[t] = (SPLIT && p.bias) ? p.bias[ch] : 0.f;
     }
@@ -211,10 +222,11 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
             acc[j] = (floatx4){b0, b0, b0, b0};
         }
         if constexpr (SPLIT) {
-            const int half = wave & 1, cgp = wave >> 1;
+            const int half = wave % PQ, cgp = wave / PQ;
             const float* xb = Xs + (size_t)buf * NG * SK_TP * 4 + (size_t)(half * 32 + fr) * 4 + fk;
             const float* wp = Ws + (size_t)(cgp * QT * 16 + fr) * 4 + fk;                      // primal tiles of this wave
             const float* wd = Ws + (size_t)((CT / 2 + cgp * QT) * 16 + fr) * 4 + fk;             // dual tiles
+            const float* wd2 = Ws + (size_t)(NGP_T * BC + cgp * QT * 16 + fr) * 4 + fk;         // dual tiles, groups >= NGP
 #pragma unroll
             for (int g = 0; g < NG_T; ++g) {
                 const float a0 = xb[(size_t)g * SK_TP * 4], a1 = xb[(size_t)g * SK_TP * 4 + 64];
@@ -228,7 +240,8 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
                 }
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
-                    const float b = wd[((size_t)g * BC + t * 16) * 4];
+                    const float b = g < NGP_T ? wd[((size_t)g * BC + t * 16) * 4]
+                                              : wd2[((size_t)(g - NGP_T) * (BC / 2) + t * 16) * 4];
                     acc[QT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[QT + t], 0, 0, 0);
                     acc[3 * QT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[3 * QT + t], 0, 0, 0);
                 }
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
         auto store_tile = [&]() __attribute__((always_inline)) {
             if constexpr (SPLIT) {
                 // lane owns channel TJ*16+fr, positions tile*64 + half*32 + sub*16 + fk*4 .. +3 for sub = 0, 1
-                const int half = wave & 1, cgp = wave >> 1;
+                const int half = wave % PQ, cgp = wave / PQ;
                 const unsigned pos = (unsigned)(tile * SK_TP) + half * 32 + fk * 4;
                 const unsigned img = pos / (unsigned)p.dstS;
                 const unsigned rem = pos - img * (unsigned)p.dstS;
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(SK_NW * 64) void hc_conv_smallk_kernel(const ConvP 
         if constexpr (SPLIT) {
             for (int t = tid; t < SK_NW * BC * 2; t += SK_NT) red[t] = 0.f;       // a wave fills its own tiles only
             __syncthreads();
-            const int cgp = wave >> 1;
+            const int cgp = wave / PQ;
 #pragma unroll
             for (int t = 0; t < 2 * QT; ++t) {
                 const int ch = (t < QT ? cgp * QT + t : CT / 2 + cgp * QT + (t - QT)) * 16 + fr;
@@ -364,20 +377,24 @@ template <int CT, int NW>
 static int launch_smallk(const ConvP& p, int NG, int NGP, hipStream_t st) {
     constexpr int TP = SkGeom<NW>::TP, NT = SkGeom<NW>::NT;
     const long long ntiles = (p.Ptot + TP - 1) / TP;
-    const size_t smem = ((size_t)NG * CT * 16 * 4 + (size_t)(NW == 8 ? 2 : 1) * NG * TP * 4) * sizeof(float);
-    const long long want = 256 * (8 / NW);                 // one 8-wave or two 4-wave workgroups per CU
-    const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
+    const size_t smem_generic = ((size_t)NG * CT * 16 * 4 + (size_t)(NW == 8 ? 2 : 1) * NG * TP * 4) * sizeof(float);
 #define SELD_SK(KH_, KW_, NG_, NGP_)                                                                               \
     do {                                                                                                           \
         auto kern = hc_conv_smallk_kernel<CT, KH_, KW_, NW, NG_, NGP_>;                                            \
+        constexpr bool split = NG_ && (NGP_ * 2 == NG_) && (CT % 4 == 0);                                          \
+        const size_t smem = split ? ((size_t)(NGP_ * CT * 16 + (NG_ - NGP_) * CT * 8) * 4 + (size_t)NG_ * TP * 4) * sizeof(float) \
+                                  : smem_generic;                                                                   \
+        long long want = (split || NW == 4) ? 512 : 256;       /* two workgroups per CU, or one 8-wave workgroup */   \
+        if (const char* e = getenv("SELD_SMALLK_WGS")) want = atoll(e);                                            \
+        const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);                                           \
         if (smem > 64 * 1024 &&                                                                                    \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return SELD_ELAUNCH;                                                                                   \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p, NG, NGP, ntiles);                              \
     } while (0)
     if (p.KH == 1 && p.KW == 3) SELD_SK(1, 3, 0, 0);
-    else if (p.KH == 3 && p.KW == 3 && NG == 18 && NGP == 9 && p.Ktot == 72 && p.dstS % 64 == 0 && p.dstW % 64 == 0 &&
-             p.Ptot % 64 == 0 && p.KDh == 1 && p.KDw == 1) SELD_SK(3, 3, 18, 9);   // the 8-channel first layer
+    else if (p.KH == 3 && p.KW == 3 && NG == 18 && NGP == 9 && p.Ktot == 72 && p.dstS % TP == 0 && p.dstW % TP == 0 &&
+             p.Ptot % TP == 0 && p.KDh == 1 && p.KDw == 1) SELD_SK(3, 3, 18, 9);   // the 8-channel first layer
     else if (p.KH == 3 && p.KW == 3) SELD_SK(3, 3, 0, 0);
     else SELD_SK(0, 0, 0, 0);
 #undef SELD_SK
