@@ -32,6 +32,12 @@ WORKLOADS = {
                cnn_filters=[64] * 3, G=128, U=64, V=[128, 128], fc_layers=[128]),
     "c3": dict(name="DQSELD-TCN-S1-PHI_8ch", domain="DQ", domain_classifier="DQ", input_channels=8, batch=32,
                cnn_filters=[192] * 3, G=384, U=192, V=[384, 384], fc_layers=[384]),
+    # configs 4 and 5 are quoted over 4 / 8 GPUs at 16 samples per GPU; selectable for single-GPU runs
+    "c4": dict(name="DQSELD-TCN-S1-PHI_16chMagPhase", domain="DQ", domain_classifier="DQ", input_channels=16, batch=16,
+               cnn_filters=[192] * 3, G=384, U=192, V=[384, 384], fc_layers=[384]),
+    "c5": dict(name="DQSELD-TCN micAMagPhaseParallelmicBMagPhase two-stream", domain="DQ", domain_classifier="R",
+               input_channels=16, batch=16, cnn_filters=[192] * 3, G=384, U=192, V=[384, 384], fc_layers=[128],
+               parallel_ConvTC_block="2Parallel", parallel_magphase=True),
 }
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense
@@ -43,7 +49,9 @@ def model_kwargs(w, freq=128, time_dim=512):
                 kernel_size_cnn_blocks=3, pool_size=[[8, 2], [8, 2], [2, 2]], pool_time="TCN", D=[10],
                 dilation_mode="fibonacci", G=w["G"], U=w["U"], kernel_size_dilated_conv=3, spatial_dropout_rate=0.5,
                 V=w["V"], V_kernel_size=3, fc_layers=w["fc_layers"], fc_activations="linear", fc_dropout="Last",
-                dropout_perc=0.3, class_overlaps=3, use_bias_conv=0, use_bias_linear=1, batch_norm="BN")
+                dropout_perc=0.3, class_overlaps=3, use_bias_conv=0, use_bias_linear=1, batch_norm="BN",
+                parallel_ConvTC_block=w.get("parallel_ConvTC_block", "False"),
+                parallel_magphase=w.get("parallel_magphase", False))
 
 
 def pmc_traffic(kernel_label):
