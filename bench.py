@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """Train-step benchmark of the DualQ-SELD-TCN hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1|c4|c5] [--mode graph|eager]
 
-One step = zero_grad -> forward -> BCE + 5*MSE -> backward -> (all-reduce) -> Adam on one synthetic
+One step = zero_grad -> forward -> BCE + 5*MSE -> backward -> (gradient exchange) -> Adam on one synthetic
 minibatch resident in HBM.  Prints ONE JSON line (rank 0) with the whole-job samples/s, the
-roofline of the dominant kernel measured with HIP events inside the timed region, and the CPU baseline
-(the oracle timed on the host cores, rank 0, N = 1 only).
+roofline of the dominant kernel (and of the HBM-bound first-layer DualQ-Conv the north-star names) measured
+with HIP events, and the CPU baseline (the oracle timed on the host cores, rank 0, N = 1 only).
+
+`--mode graph` (default) replays the step as recorded HIP graphs (train.GraphedTrainStep): the same kernels,
+no host time between them.  HIP events cannot bracket a kernel inside a replayed graph, so the per-kernel
+roofline figures come from an instrumented EAGER pass of the same step run right after the timed region, in
+this process, on the stream the kernels are launched on (`roofline.measured_over` says so).
 
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: one process
-per GPU, RCCL all-reduce of the flat gradient buffer, weak scaling (per-GPU batch fixed).
+per GPU, two RCCL all-reduces of the flat gradient buffer per step (dp.BucketedGradSync), weak scaling
+(per-GPU batch fixed: the workload's own per-GPU batch, e.g. 16 for the 4- and 8-GPU configs c4 / c5).
 """
 import argparse
 import importlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,7 +40,7 @@ WORKLOADS = {
                cnn_filters=[64] * 3, G=128, U=64, V=[128, 128], fc_layers=[128]),
     "c3": dict(name="DQSELD-TCN-S1-PHI_8ch", domain="DQ", domain_classifier="DQ", input_channels=8, batch=32,
                cnn_filters=[192] * 3, G=384, U=192, V=[384, 384], fc_layers=[384]),
-    # configs 4 and 5 are quoted over 4 / 8 GPUs at 16 samples per GPU; selectable for single-GPU runs
+    # configs 4 and 5 are quoted over 4 / 8 GPUs at 16 samples per GPU
     "c4": dict(name="DQSELD-TCN-S1-PHI_16chMagPhase", domain="DQ", domain_classifier="DQ", input_channels=16, batch=16,
                cnn_filters=[192] * 3, G=384, U=192, V=[384, 384], fc_layers=[384]),
     "c5": dict(name="DQSELD-TCN micAMagPhaseParallelmicBMagPhase two-stream", domain="DQ", domain_classifier="R",
@@ -41,6 +49,7 @@ WORKLOADS = {
 }
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense
+FIRST_LAYER_KERNEL = "hc_conv_smallk_kernel"     # cnn.0 forward: the one HBM-bound DualQ-Conv
 
 
 def model_kwargs(w, freq=128, time_dim=512):
@@ -56,26 +65,40 @@ def model_kwargs(w, freq=128, time_dim=512):
 
 def pmc_traffic(kernel_label):
     """HBM-side bytes per launch of `kernel_label` from the committed counter passes of this same command
-    (profiles/*pmc_traffic.json, written by tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
-    runs, FETCH_SIZE doubled as the gfx950 guide prescribes), or None if the kernel was not sampled."""
+    (profiles/*pmc_traffic.json, written by tools/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` runs, FETCH_SIZE doubled as the gfx950 guide prescribes), or None if the kernel was not
+    sampled.  Counters cannot be read from inside this process: the figure is per launch of the same kernel on the
+    same workload, the file it came from is named in `traffic_source`."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
         k = json.load(open(files[-1]))["kernels"].get(kernel_label)
     except (OSError, ValueError, KeyError):
-        return None
-    return round(k["traffic_bytes"]) if k else None
+        return None, None
+    return (round(k["traffic_bytes"]) if k else None), os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(w, seconds_budget=25.0):
+def _cpu_model():
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.startswith("Model name"):
+                return line.split(":", 1)[1].strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return "unknown"
+
+
+def cpu_baseline(w, seconds_budget=14.0):
     """The oracle (CPU restatement of the reference's algorithm, `assembled` = one real conv per layer exactly as
-    quaternion_ops.py:125-147 does) timed on this host: same step definition, dropout on, bounded sample."""
+    quaternion_ops.py:125-147 does) timed on this host: same step definition, dropout on, B = min(B, 8), at all host
+    threads and at 8; a bounded sample: one warm-up step, then the median of up to 5 steps within
+    `seconds_budget` per thread setting."""
     from oracle import seld_oracle as O
     import numpy as np
     pkg = importlib.import_module(PKG)
-    batch = min(w["batch"], 4)
+    batch = min(w["batch"], 8)
     kw = model_kwargs(w)
     np.random.seed(1)
     torch.manual_seed(1)
@@ -95,24 +118,35 @@ def cpu_baseline(w, seconds_budget=25.0):
         loss = O.seld_loss(sed, doa, target, 42)
         loss.backward()
         opt.step()
-    step()                                    # warm-up
-    t0 = time.time()
-    n = 0
-    while n < 2 or (time.time() - t0 < seconds_budget and n < 8):
-        step()
-        n += 1
-    dt = time.time() - t0
-    return dict(value=round(batch * n / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} train steps of the same workload at batch {batch} (oracle, torch-CPU fp32, dropout on)")
+
+    all_threads = torch.get_num_threads()
+    runs = []
+    for threads in sorted({all_threads, min(8, all_threads)}, reverse=True):
+        torch.set_num_threads(threads)
+        step()                                # warm-up
+        times, t_begin = [], time.time()
+        while len(times) < 2 or (time.time() - t_begin < seconds_budget and len(times) < 5):
+            t0 = time.time()
+            step()
+            times.append(time.time() - t0)
+        runs.append(dict(threads=threads, value=round(batch / statistics.median(times), 3), steps=len(times)))
+    torch.set_num_threads(all_threads)
+    best = max(runs, key=lambda r: r["value"])
+    return dict(value=best["value"], unit="samples/s", cores=best["threads"], kind="port", cpu=_cpu_model(),
+                host_threads=all_threads, runs=runs,
+                sample=f"median of {best['steps']} train steps (after 1 warm-up) of the same workload at batch {batch} "
+                       f"(oracle, torch-CPU fp32, dropout on); `runs` lists every thread setting, `value` is the faster")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--mode", default=os.environ.get("SELD_BENCH_MODE", "graph"), choices=["graph", "eager"])
+    ap.add_argument("--roofline-steps", type=int, default=5, help="instrumented eager steps after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -136,93 +170,135 @@ def main():
     import numpy as np
     np.random.seed(1)
     torch.manual_seed(1)
+    DP.seed_rank_streams(rank)
     model = pkg.model.SELD_Model(**model_kwargs(w)).to(dev).train()
-    opt = T.FlatAdam(model.parameters(), lr=1e-4)
+    opt = T.FlatAdam(model.parameters(), lr=1e-4, late=DP.late_parameters(model) if world > 1 else None)
     DP.broadcast_parameters(opt.flat_param)
-    sync = DP.FlatGradSync(flat_grad=opt.flat_grad)
+    sync = DP.BucketedGradSync(opt, model)
     x, target = T.synthetic_batch(batch, w["input_channels"], 128, 512, 42, 1234 + rank, dev)
 
-    def step():
+    def eager_step():
         return DP.dp_train_step(model, opt, sync, x, target, 42, T.seld_loss_fn)
 
-    # Warm-up doubles as the per-kernel survey: every conv launch is bracketed by HIP events to find the dominant
-    # kernel.  In the timed region only THAT kernel's launches are bracketed (a few per step), so the event records
-    # do not perturb the throughput being measured (bracketing all ~140 launches costs ~4 %).
-    # The survey runs with the weight-gradient side stream off: kernels that overlap on two queues stretch each other's
-    # event brackets, and the survey is about which kernel costs most by itself.  The timed region runs the product
-    # configuration (side stream on); its bracketed kernel is a forward one, which nothing overlaps.
+    # ---- warm-up = per-kernel survey: every conv launch of steps 1..W-1 is bracketed by HIP events (step 0 is cold:
+    # module load, allocator growth) to find the dominant kernel.  The survey runs with the weight-gradient side
+    # stream off: kernels that overlap on two queues stretch each other's brackets, and the survey is about which
+    # kernel costs most by itself.
     survey = {}
     side_env = os.environ.get("SELD_WGRAD_SIDE_STREAM")
-    if not args.no_kernel_timer and args.warmup > 0:
+    timing = not args.no_kernel_timer
+    n_warm = max(args.warmup, 2 if timing else 0)
+    for i in range(n_warm):
+        if timing and i == 1:
+            torch.cuda.synchronize()
+            H.kernel_timer.reset()
+            H.kernel_timer.only = None
+            H.kernel_timer.active = True
+            os.environ["SELD_WGRAD_SIDE_STREAM"] = "0"
+        eager_step()
+    torch.cuda.synchronize()
+    if timing:
+        H.kernel_timer.active = False
+        survey = H.kernel_timer.summary()
         H.kernel_timer.reset()
-        H.kernel_timer.only = None
-        H.kernel_timer.active = True
-        os.environ["SELD_WGRAD_SIDE_STREAM"] = "0"
-    for _ in range(args.warmup):
-        step()
-    if side_env is None:
-        os.environ.pop("SELD_WGRAD_SIDE_STREAM", None)
+        if side_env is None:
+            os.environ.pop("SELD_WGRAD_SIDE_STREAM", None)
+        else:
+            os.environ["SELD_WGRAD_SIDE_STREAM"] = side_env
+    dominant = max(survey, key=lambda k: survey[k]["ms"]) if survey else None
+
+    if args.mode == "graph":
+        runner = T.GraphedTrainStep(model, opt, x, target, 42, 1.0, 5.0, sync=sync, warmup=1)
+        step = runner
+        step()                      # one replay outside the timed region
     else:
-        os.environ["SELD_WGRAD_SIDE_STREAM"] = side_env
+        step = eager_step
+
+    # ---- timed region: exactly K steps between barrier + synchronize; an event after every step gives the per-step
+    # times (median) without a host synchronisation inside the region
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    if H.kernel_timer.active:
-        H.kernel_timer.active = False
-        survey = H.kernel_timer.summary()
-    dominant = max(survey, key=lambda k: survey[k]["ms"]) if survey else None
-    H.kernel_timer.reset()
-    H.kernel_timer.only = {dominant} if dominant else None
-    H.kernel_timer.active = not args.no_kernel_timer
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
-    H.kernel_timer.active = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+
+    # ---- roofline pass: the same step, eager, only the dominant kernel and the first-layer DualQ-Conv bracketed
+    summ = {}
+    if timing and dominant and args.roofline_steps > 0:
+        first = next((k for k in survey if k.startswith(FIRST_LAYER_KERNEL)), None)
+        H.kernel_timer.only = {dominant} | ({first} if first else set())
+        H.kernel_timer.active = True
+        for _ in range(args.roofline_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        H.kernel_timer.active = False
+        summ = H.kernel_timer.summary()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
             "metric": "train-step samples/sec (8ch x 128mel x 512T)", "value": round(batch * world * args.steps / elapsed, 3),
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm, "ms_per_step": round(ms, 3),
+            "ms_per_step_median": round(statistics.median(per_step), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['name']} train step, F=128 T=512 (U=L={w['U']}, SURVEY F3), "
                                    f"batch {batch}/GPU, random-init weights", "global_batch": batch * world,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "step_mode": args.mode},
             "loss": round(final_loss, 6),
         }
-        summ = H.kernel_timer.summary()
         if summ:
             def rates(label, d, nsteps):
                 tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 gb = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                 return dict(kernel=label, calls_per_step=d["calls"] / nsteps, ms_per_step=round(d["ms"] / nsteps, 4),
                             avg_us=round(d["ms"] / d["calls"] * 1e3, 2), tflops=round(tf, 2), gbs=round(gb, 1))
-            label = max(summ, key=lambda k: summ[k]["ms"])
-            d = summ[label]
-            dom = rates(label, d, args.steps)
-            # roof that bounds the dominant kernel: compare time at each peak
-            t_hbm = d["bytes"] / (PEAK_HBM_GBS * 1e9)
-            t_mfma = d["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12)
-            if t_hbm >= t_mfma:
-                roof = dict(bound="hbm", achieved=dom["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
-                            frac=round(dom["gbs"] / PEAK_HBM_GBS, 4))
-            else:
-                roof = dict(bound="mfma", achieved=dom["tflops"], peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4))
-            roof.update(kernel=dom["kernel"], avg_launch_us=dom["avg_us"], launches_per_step=dom["calls_per_step"],
-                        traffic=pmc_traffic(dom["kernel"]))
-            out["roofline"] = roof
-            # the other conv kernels: measured during the warm-up steps (every launch bracketed there)
-            per = [rates(k, v, max(args.warmup, 1)) for k, v in survey.items()] if survey else [dom]
+
+            def roofline(label):
+                d = summ[label]
+                r = rates(label, d, args.roofline_steps)
+                # roof that bounds the kernel: compare time at each peak
+                t_hbm = d["bytes"] / (PEAK_HBM_GBS * 1e9)
+                t_mfma = d["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+                if t_hbm >= t_mfma:
+                    roof = dict(bound="hbm", achieved=r["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
+                                frac=round(r["gbs"] / PEAK_HBM_GBS, 4))
+                else:
+                    roof = dict(bound="mfma", achieved=r["tflops"], peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                                frac=round(r["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4))
+                traffic, src = pmc_traffic(label)
+                roof.update(kernel=label, avg_launch_us=r["avg_us"], launches_per_step=r["calls_per_step"],
+                            traffic=traffic, traffic_source=src,
+                            measured_over=f"{args.roofline_steps} instrumented eager steps after the timed region "
+                                          f"(HIP events on the launch stream)")
+                return roof, d
+            if dominant in summ:
+                out["roofline"], _ = roofline(dominant)
+            first = next((k for k in summ if k.startswith(FIRST_LAYER_KERNEL)), None)
+            if first and first != dominant:
+                # the north-star's own target shape (first-layer DualQ-Conv forward), priced against HBM whatever the
+                # formula above says: AI 26 puts it next to the ridge (19.7 flop/B)
+                r, d = roofline(first)
+                gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                r.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                         frac=round(gbs / PEAK_HBM_GBS, 4),
+                         tflops=round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2))
+                out["roofline_hbm"] = r
+            # the other conv kernels: measured during warm-up steps 1..W-1 (every launch bracketed there)
+            per = [rates(k, v, max(n_warm - 1, 1)) for k, v in survey.items()]
             per.sort(key=lambda r: -r["ms_per_step"])
             out["conv_kernels"] = per[:8]
         if world == 1 and not args.no_cpu_baseline:

@@ -31,6 +31,11 @@ extern "C" {
 int         seld_abi_version(void);          /* bumps on any signature change                      */
 const char* seld_build_arch(void);           /* "gfx950"                                           */
 int         seld_last_hip_error(void);       /* last hipError_t seen by a launch in this thread    */
+/* The SELD_* environment switches (csrc/env.h: kernel-generation selection, all result-preserving) are read once at
+ * first use; seld_env_reload re-reads them.  seld_tuning_build: 1 if the library was compiled with -DSELD_TUNING,
+ * which adds timing-experiment switches that produce WRONG results (never set for the shipped library). */
+int         seld_env_reload(void);
+int         seld_tuning_build(void);
 
 /* ------------------------------------------------------------------------------------------
  * Hypercomplex convolution.  Replaces quaternion_conv (quaternion_ops.py:125-147),
@@ -270,8 +275,12 @@ int seld_maxpool_bwd(const float* dy, const uint8_t* idx, int64_t NC, int32_t H,
 
 /* dropout with a Philox-4x32-10 counter RNG: element i is kept iff u(seed, offset + i/4)[i%4] >= p.
  * `per_channel` (Dropout1d): one decision per (n, c) row of length S.  y = x * keep / (1 - p). */
-int seld_dropout_fwd(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, float* y, void* stream);
-int seld_dropout_mask_rows(int64_t rows, float p, uint64_t seed, uint64_t offset, float* mask, void* stream);
+/* `state` (nullable): device-resident step state (seld_step_begin below); state[0] is added to `offset`, so a launch
+ * recorded in a HIP graph draws fresh numbers at every replay. */
+int seld_dropout_fwd(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* state,
+                     float* y, void* stream);
+int seld_dropout_mask_rows(int64_t rows, float p, uint64_t seed, uint64_t offset, const uint64_t* state,
+                           float* mask, void* stream);
 
 /* y = a + b ; y += b */
 int seld_add(const float* a, const float* b, int64_t n, float* y, void* stream);
@@ -314,15 +323,34 @@ int seld_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float grad_scale, void* stream);
 
+/* Device-resident step state, so that one training step (train.py:552-560) can be recorded once as a HIP graph and
+ * replayed: 4 x uint64 = { Philox base added to every dropout offset, optimiser step (1-based), learning rate (float
+ * bits in the low word), Philox draws per step }.
+ * seld_step_begin replaces `optimizer.zero_grad()` (train.py:552): zeroes the flat gradient buffer (n floats, 16-byte
+ * aligned) and, if state is non-null, advances state[0] += state[3], state[1] += 1.
+ * seld_adam_flat_state is seld_adam_flat with step = state[1] and lr = state[2]. */
+int seld_step_begin(float* flat_grad, int64_t n, uint64_t* state, void* stream);
+int seld_adam_flat_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                         const uint64_t* state, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * STFT magnitude / phase (utility_functions.py:129-155 = scipy.signal.stft(window='hamming',
  * boundary='zeros', padded=True) -> abs/angle -> drop DC bin -> drop last frame).
  * x (C, L) fp32; out (C or 2C, nperseg/2, frames-1) fp32, phase channels after magnitude channels.
- * nperseg must be a power of two <= 512 (the reference uses 512).
+ * nperseg must be a power of two <= 4096 (the reference uses 512).
  * ------------------------------------------------------------------------------------------ */
 int seld_stft_frames(int32_t L, int32_t nperseg, int32_t noverlap);   /* frames AFTER the cut */
 int seld_stft_magphase(const float* x, int32_t C, int32_t L, int32_t nperseg, int32_t noverlap,
                        int32_t output_phase, float* out, void* stream);
+/* The same with every argument of spectrum_fast (utility_functions.py:129-130): cut_dc = 0 keeps all nperseg/2 + 1
+ * bins, cut_last_timeframe = 0 keeps the last frame; `window` (nullable, device, nperseg floats) = window values
+ * already divided by their sum (scipy's scaling='spectrum'), null = periodic Hamming (window='hamming').
+ * out (C or 2C, nperseg/2 + 1 - cut_dc, seld_stft_frames_ex(...)). */
+int seld_stft_frames_ex(int32_t L, int32_t nperseg, int32_t noverlap, int32_t cut_last_timeframe);
+int seld_stft_magphase_ex(const float* x, int32_t C, int32_t L, int32_t nperseg, int32_t noverlap,
+                          int32_t output_phase, int32_t cut_dc, int32_t cut_last_timeframe,
+                          const float* window, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dataset normalisation, in place on a resident predictor array x (items, channels, hw) fp32

@@ -6,4 +6,4 @@ The directory name is not a Python identifier; import it with
 """
 from . import _lib  # noqa: F401
 from . import hip_ops  # noqa: F401
-from . import hip_nn, model, train, dp  # noqa: F401,E402
+from . import hip_nn, model, train, dp, utility_functions  # noqa: F401,E402

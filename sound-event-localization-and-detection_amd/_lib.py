@@ -45,6 +45,11 @@ def lib():
     return _lib
 
 
+def reload_env():
+    """Make the library re-read its SELD_* environment switches (it reads them once, at first use)."""
+    check(lib().seld_env_reload(), "seld_env_reload")
+
+
 def check(rc, what):
     if rc != SELD_OK:
         extra = ""

@@ -1,0 +1,29 @@
+// Environment switches of libseld_hip.so, read ONCE (first use) into a validated table; seld_env_reload() re-reads
+// them (the tests switch kernel generations inside one process).
+//
+// Selection switches -- every setting computes the same results, they only choose which kernel generation runs
+// (the test suite uses them to cover every generation):
+//   SELD_CONV_CFG=ct,pt   force the convolution tile (one of the candidates of pick_cfg, anything else is ignored)
+//   SELD_CONV_NOVEC / SELD_CONV_NOFAST / SELD_CONV_NO_SMALLK / SELD_NO_FWD_PAIR / SELD_CONV_PAIR / SELD_CONV_NO_PERM
+//   SELD_WGRAD_NOROW / SELD_WGRAD_SLOW / SELD_WGRAD_CFG=0..4 / SELD_WGRAD_WGS=n / SELD_SMALLK_WGS=n
+//   SELD_MHA_NO_MFMA
+// Timing-experiment switches that switch parts of a kernel OFF and therefore give WRONG results exist only in
+// builds compiled with -DSELD_TUNING (never the shipped library):
+//   SELD_VEC_DBG, SELD_WGRAD_DBG, SELD_SMALLK_DBG, SELD_SMALLK_NW
+#pragma once
+
+namespace seld {
+
+struct SeldEnv {
+    int conv_cfg_ct = 0, conv_cfg_pt = 0;          // 0 = not forced
+    bool conv_novec = false, conv_nofast = false, conv_no_smallk = false, no_fwd_pair = false, conv_pair = false;
+    bool conv_no_perm = false;                      // SELD_CONV_NO_PERM: contiguous channel tiles in hc_conv_vec_kernel
+    bool wgrad_norow = false, wgrad_slow = false, mha_no_mfma = false;
+    int wgrad_cfg = -1;                             // -1 = not forced, else 0..4
+    long long wgrad_wgs = 0, smallk_wgs = 0;        // 0 = default
+    int vec_dbg = 0, wgrad_dbg = 0, smallk_dbg = 0, smallk_nw = 4;   // SELD_TUNING builds only; otherwise the defaults
+};
+
+const SeldEnv& env();      // abi.hip
+
+}  // namespace seld

@@ -464,12 +464,9 @@ struct TileCfg { int ct, pt; };
 static TileCfg pick_cfg(int C, long long P) {
     static const TileCfg cand[] = {{12, 1}, {12, 2}, {6, 1}, {4, 4}, {2, 4}, {1, 4}};
     static const double pref[] = {1.00, 0.95, 0.80, 0.75, 0.45, 0.30};   // measured ranking on the config-3 layers
-    if (const char* e = getenv("SELD_CONV_CFG")) {
-        int a = 0, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2)
-            for (const TileCfg& c : cand)
-                if (c.ct == a && c.pt == b) return c;
-    }
+    if (env().conv_cfg_ct)
+        for (const TileCfg& c : cand)
+            if (c.ct == env().conv_cfg_ct && c.pt == env().conv_cfg_pt) return c;
     double best = -1.0;
     TileCfg pick = cand[3];
     for (int i = 0; i < 6; ++i) {
@@ -509,7 +506,7 @@ static void launch_conv(const ConvP& p, hipStream_t st) {
     const int KK = p.KH * p.KW;
     const int CK = (MODE == MODE_FWD ? p.IA : p.OA) * KK;
     const bool fast = (MODE == MODE_FWD || p.wt) && (CK % 4 == 0) && CK >= 16 && p.SDh == 1 && p.SDw == 1 &&
-                      !getenv("SELD_CONV_NOFAST");
+                      !env().conv_nofast;
     if (fast && p.KH == 1 && p.KW == 1) hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 1, 1, MODE, 1>), grid, dim3(256), 0, st, p);
     else if (fast && p.KH == 1 && p.KW == 3) hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 1, 3, MODE, 1>), grid, dim3(256), 0, st, p);
     else if (fast && p.KH == 3 && p.KW == 3) hipLaunchKernelGGL((hc_conv_kernel<CT, PT, 3, 3, MODE, 1>), grid, dim3(256), 0, st, p);
@@ -532,7 +529,7 @@ int hc_conv_smallk_try(const ConvP& p, hipStream_t st, int* rc, int dry_run);
 
 static void fill_common(ConvP& p, const seld_conv_desc* d, const float* const w[8]) {
     p.algebra = d->algebra;
-    p.pairing = getenv("SELD_CONV_PAIR") ? 1 : 0;   // measured 5-14 % slower on the TCN layers: off by default
+    p.pairing = env().conv_pair ? 1 : 0;   // measured 5-14 % slower on the TCN layers: off by default
     p.KH = d->k[0]; p.KW = d->k[1];
     p.OA = d->Cout / d->algebra; p.IA = d->Cin / d->algebra;
     for (int i = 0; i < 8; ++i) p.w.p[i] = (w && i < d->algebra) ? w[i] : nullptr;
@@ -594,7 +591,7 @@ extern "C" int seld_hc_conv_fwd_ex(const seld_conv_desc* d, const float* x, cons
     p.epilogue = epilogue;
     p.src = x; p.bias = bias; p.dst = y; p.addend = addend; p.stats = stats;
     int rc2 = SELD_OK;
-    if (const char* e = getenv("SELD_SMALLK_DBG")) p.wt = atoi(e);
+    p.wt = env().smallk_dbg;          // non-zero only in -DSELD_TUNING builds (timing experiments)
     if (hc_conv_smallk_try(p, (hipStream_t)stream, &rc2, 0)) return rc2;       // short reductions: persistent kernel
     return run_conv<MODE_FWD>(p, (hipStream_t)stream);
 }
@@ -718,7 +715,7 @@ extern "C" int seld_hc_conv_pair_fwd(const seld_conv_desc* d, const float* x, co
     for (int i = 0; i < 8; ++i) p.w2.p[i] = (i < d->algebra) ? wB[i] : nullptr;
     p.epilogue2 = epilogueB; p.src2 = x; p.bias2 = biasB; p.dst2 = yB; p.addend2 = addendB; p.stats2 = statsB;
     const TileCfg c = pick_cfg(p.Cdst, p.Ptot);
-    if (!getenv("SELD_NO_FWD_PAIR") && hc_conv_vec_try(p, MODE_FWD, c.ct, c.pt, (hipStream_t)stream)) return check_launch();
+    if (!env().no_fwd_pair && hc_conv_vec_try(p, MODE_FWD, c.ct, c.pt, (hipStream_t)stream)) return check_launch();
     rc = seld_hc_conv_fwd_ex(d, x, wA, biasA, yA, epilogueA, addendA, statsA, stream);
     if (rc) return rc;
     return seld_hc_conv_fwd_ex(d, x, wB, biasB, yB, epilogueB, addendB, statsB, stream);
@@ -810,7 +807,7 @@ extern "C" int seld_hc_conv_kernel_label(const seld_conv_desc* d, int32_t which,
     }
     const int CKl = ((which == 0 ? d->Cin : d->Cout) / d->algebra) * d->k[0] * d->k[1];
     const bool fast = (CKl % 4 == 0) && CKl >= 16 && (which == 0 || (d->stride[0] == 1 && d->stride[1] == 1)) && kh != 0 &&
-                      !getenv("SELD_CONV_NOFAST");
+                      !env().conv_nofast;
     snprintf(buf, buflen, "hc_conv_kernel<%d, %d, %d, %d, %d, %d>", c.ct, c.pt, fast ? kh : 0, fast ? kw : 0, which, fast ? 1 : 0);
     return SELD_OK;
 }

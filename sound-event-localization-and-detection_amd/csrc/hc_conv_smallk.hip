@@ -385,7 +385,7 @@ static int launch_smallk(const ConvP& p, int NG, int NGP, hipStream_t st) {
         const size_t smem = split ? ((size_t)(NGP_ * CT * 16 + (NG_ - NGP_) * CT * 8) * 4 + (size_t)NG_ * TP * 4) * sizeof(float) \
                                   : smem_generic;                                                                   \
         long long want = (split || NW == 4) ? 512 : 256;       /* two workgroups per CU, or one 8-wave workgroup */   \
-        if (const char* e = getenv("SELD_SMALLK_WGS")) want = atoll(e);                                            \
+        if (env().smallk_wgs) want = env().smallk_wgs;                                                             \
         const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);                                           \
         if (smem > 64 * 1024 &&                                                                                    \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
@@ -404,7 +404,7 @@ static int launch_smallk(const ConvP& p, int NG, int NGP, hipStream_t st) {
 // Returns the channel-tile count if the call is (dry_run: would be) handled here (rc in *rc), 0 if the general
 // kernel must be used.
 int hc_conv_smallk_try(const ConvP& p, hipStream_t st, int* rc, int dry_run) {
-    if (getenv("SELD_CONV_NO_SMALLK")) return 0;
+    if (env().conv_no_smallk) return 0;
     if (p.mode != MODE_FWD || p.SDh != 1 || p.SDw != 1 || p.SMh != 1 || p.SMw != 1) return 0;
     if (p.Ktot > 160 || (p.epilogue & ~SELD_EPI_STATS)) return 0;
     if (p.dstS % 4 || p.Ptot >= (1LL << 31) || p.src_elems * 4 >= (1LL << 32)) return 0;
@@ -417,7 +417,7 @@ int hc_conv_smallk_try(const ConvP& p, hipStream_t st, int* rc, int dry_run) {
     else if (p.Cdst == 128) ct = 8;
     else if (p.Cdst == 64) ct = 4;
     else return 0;
-    const int nw = (getenv("SELD_SMALLK_NW") && atoi(getenv("SELD_SMALLK_NW")) == 8) ? 8 : 4;
+    const int nw = env().smallk_nw;        // 8 only in -DSELD_TUNING builds (untested tuning variant)
     const size_t smem = ((size_t)NG * ct * 16 * 4 + (size_t)(nw == 8 ? 2 : 1) * NG * nw * 16 * 4) * sizeof(float);
     if (smem * (8 / nw) > 156 * 1024) return 0;
     if (dry_run) return ct;

@@ -450,7 +450,7 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, Wgrad
     }
     // resident workgroups per CU (LDS-limited): 128x128 / 192x80 / 96x128 -> 2, 64x80 -> 3, 64x64 -> 4
     long long slots = (bm == 64 ? (bn == 64 ? 4 : 3) : 2) * 256;
-    if (const char* e = getenv("SELD_WGRAD_WGS")) slots = atoll(e) > 0 ? atoll(e) : slots;
+    if (env().wgrad_wgs) slots = env().wgrad_wgs;
     tiles *= (p->nslots > 1 ? 2 : 1);                     // a pair launch carries two gradients
     long long want = slots / tiles;                       // floor: stay within one generation
     const long long maxs = (Ptot + 511) / 512;            // at least 512 positions per split
@@ -469,7 +469,7 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, Wgrad
 // 3 = 96 x 128, 4 = 64 x 80 (short K: a third of the float-atomic chain per gradient element of 192 x 80, x re-read 3x)
 static int wgrad_cfg(const seld_conv_desc* d) {
     const int Ktot = d->Cin * d->k[0] * d->k[1];
-    if (const char* e = getenv("SELD_WGRAD_CFG")) return atoi(e);     // tuning aid
+    if (env().wgrad_cfg >= 0) return env().wgrad_cfg;     // tuning aid, validated 0..4
     if (Ktot <= 80 && d->Cout > 64) return (d->Cout % 64 == 0) ? 4 : 1;
     if (d->Cout <= 64 || Ktot <= 64) return 2;
     // few 128 x 128 tiles and a short reduction (positions / 512 splits at most): take 64 x 64 tiles so that
@@ -490,7 +490,7 @@ bool hc_wgrad_row_ok(const WgradP& p);
 void hc_wgrad_row_launch(const WgradP& p, int cfg, hipStream_t st);
 
 static bool wgrad_fast_ok(const WgradP& p) {
-    return (p.outW % 4 == 0) && p.outW >= 32 && p.sw == 1 && !getenv("SELD_WGRAD_SLOW");
+    return (p.outW % 4 == 0) && p.outW >= 32 && p.sw == 1 && !env().wgrad_slow;
 }
 
 template <int WRW, int RT, int CTL>
@@ -595,7 +595,7 @@ int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
     const char* t = cfg == 0 ? "2, 4, 4" : (cfg == 1 ? "4, 3, 5" : (cfg == 3 ? "2, 3, 4" : (cfg == 4 ? "4, 1, 5" : "2, 2, 2")));
     int o[2];
     hc_out_shape(d, o);
-    const bool fast = (o[1] % 4 == 0) && o[1] >= 32 && d->stride[1] == 1 && !getenv("SELD_WGRAD_SLOW");
+    const bool fast = (o[1] % 4 == 0) && o[1] >= 32 && d->stride[1] == 1 && !env().wgrad_slow;
     WgradP p{};
     p.KH = d->k[0]; p.KW = d->k[1]; p.sw = d->stride[1]; p.outW = o[1]; p.split_len = 32;
     p.Cout = d->Cout; p.Cin = d->Cin; p.outS = o[0] * o[1]; p.inS = d->in[0] * d->in[1];

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
 }
 
 bool hc_wgrad_row_ok(const WgradP& p) {
-    if (getenv("SELD_WGRAD_NOROW")) return false;
+    if (env().wgrad_norow) return false;
     const bool taps = (p.KH == 1 && p.KW == 1) || (p.KH == 1 && p.KW == 3) || (p.KH == 3 && p.KW == 3);
     return taps && p.sw == 1 && (p.outW % 32 == 0) && (p.split_len % 32 == 0) &&
            (long long)p.Cout * p.outS < (1LL << 29) && (long long)p.Cin * p.inS < (1LL << 29);
@@ -310,7 +310,7 @@ static void launch_row(const WgradP& p, hipStream_t st) {
 // cfg as in wgrad_cfg(): 0 = 128 x 128, 1 = 192 x 80, 2 = 64 x 64, 3 = 96 x 128, 4 = 64 x 80
 void hc_wgrad_row_launch(const WgradP& p_in, int cfg, hipStream_t st) {
     WgradP p = p_in;
-    p.dbg = getenv("SELD_WGRAD_DBG") ? atoi(getenv("SELD_WGRAD_DBG")) : 0;
+    p.dbg = env().wgrad_dbg;            // non-zero only in -DSELD_TUNING builds (timing experiments, wrong results)
     if (cfg == 0) launch_row<2, 4, 4>(p, st);
     else if (cfg == 1) launch_row<4, 3, 5>(p, st);
     else if (cfg == 3) launch_row<2, 3, 4>(p, st);

@@ -16,6 +16,7 @@
 //   dK/dV   : S[q][key] = Q^T K, dP[q][key] = dO^T V -> P, dS                              -> dV^T[d][key] += dO P,
 //                                                                                             dK^T[d][key] += Q  dS
 #include "common.h"
+#include "env.h"
 
 namespace seld {
 
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const float* __re
 }
 
 bool mha_mfma_ok(int T, int hd) {
-    return (hd == 16 || hd == 32 || hd == 48 || hd == 64) && T % 16 == 0 && !getenv("SELD_MHA_NO_MFMA");
+    return (hd == 16 || hd == 32 || hd == 48 || hd == 64) && T % 16 == 0 && !env().mha_no_mfma;
 }
 
 template <int HD>

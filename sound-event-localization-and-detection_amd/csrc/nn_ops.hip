@@ -497,8 +497,12 @@ __device__ __forceinline__ uint4 philox4x32_10(uint64_t counter, uint64_t key) {
 }
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 
+// `state` (nullable): the device-resident step state of seld_step_begin; state[0] is added to `offset`, so that a
+// launch recorded in a HIP graph draws fresh numbers at every replay.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, long long n, float p, float scale,
-                                                      uint64_t seed, uint64_t offset, float* __restrict__ y) {
+                                                      uint64_t seed, uint64_t offset, const uint64_t* __restrict__ state,
+                                                      float* __restrict__ y) {
+    if (state) offset += state[0];
     const long long groups = (n + 3) >> 2;
     for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
         const uint4 r = philox4x32_10(offset + (uint64_t)gi, seed);
@@ -518,7 +522,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 }
 
 __global__ void dropout_mask_rows_kernel(long long rows, float p, float scale, uint64_t seed, uint64_t offset,
-                                         float* __restrict__ mask) {
+                                         const uint64_t* __restrict__ state, float* __restrict__ mask) {
+    if (state) offset += state[0];
     const long long groups = (rows + 3) >> 2;
     for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
         const uint4 r = philox4x32_10(offset + (uint64_t)gi, seed);
@@ -599,6 +604,45 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = pv - (lr / bc1) * (mi / denom);
     }
+}
+
+// The same update with the step number and the learning rate read from the device-resident step state
+// (state[1] = 1-based step, low 32 bits of state[2] = lr as float bits): a launch recorded in a HIP graph then follows
+// the optimiser's bias correction and the scheduler's learning rate from replay to replay.
+__global__ __launch_bounds__(256) void adam_state_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, long long n,
+                                                         float b1, float b2, float eps, float wd, float gscale,
+                                                         const uint64_t* __restrict__ state) {
+    const float step = (float)state[1];
+    const float lr = __uint_as_float((unsigned)state[2]);
+    const float bc1 = 1.0f - powf(b1, step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(b2, step));
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float grad = g[i] * gscale;
+        const float pv = p[i];
+        if (wd != 0.f) grad += wd * pv;
+        const float mi = b1 * m[i] + (1.f - b1) * grad;
+        const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pv - (lr / bc1) * (mi / denom);
+    }
+}
+
+// Start of a training step: zero the flat gradient buffer (16-byte stores) and advance the step state
+//   state[0] += state[3]   Philox base (state[3] = draws per step, set by the host once it is known)
+//   state[1] += 1          optimiser step
+__global__ __launch_bounds__(256) void step_begin_kernel(float* __restrict__ g, long long n, uint64_t* __restrict__ state) {
+    if (state && blockIdx.x == 0 && threadIdx.x == 0) {
+        state[0] += state[3];
+        state[1] += 1;
+    }
+    const long long n4 = n >> 2;
+    float4* g4 = reinterpret_cast<float4*>(g);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) g[(n4 << 2) + threadIdx.x] = 0.f;
 }
 
 // one wave per row, 4 rows per block
@@ -781,18 +825,19 @@ extern "C" int seld_maxpool_bwd(const float* dy, const uint8_t* idx, int64_t NC,
     return check_launch();
 }
 
-extern "C" int seld_dropout_fwd(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, float* y,
-                                void* stream) {
+extern "C" int seld_dropout_fwd(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset,
+                                const uint64_t* state, float* y, void* stream) {
     if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return SELD_EINVAL;
     if (n == 0) return SELD_OK;
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, ST(stream), x, (long long)n, p,
-                       1.0f / (1.0f - p), seed, offset, y);
+                       1.0f / (1.0f - p), seed, offset, state, y);
     return check_launch();
 }
-extern "C" int seld_dropout_mask_rows(int64_t rows, float p, uint64_t seed, uint64_t offset, float* mask, void* stream) {
+extern "C" int seld_dropout_mask_rows(int64_t rows, float p, uint64_t seed, uint64_t offset, const uint64_t* state,
+                                      float* mask, void* stream) {
     if (!mask || rows <= 0 || p < 0.f || p >= 1.f) return SELD_EINVAL;
     hipLaunchKernelGGL(dropout_mask_rows_kernel, dim3(grid_for((rows + 3) / 4)), dim3(256), 0, ST(stream), (long long)rows,
-                       p, 1.0f / (1.0f - p), seed, offset, mask);
+                       p, 1.0f / (1.0f - p), seed, offset, state, mask);
     return check_launch();
 }
 
@@ -827,5 +872,21 @@ extern "C" int seld_adam_flat(float* param, const float* grad, float* exp_avg, f
     const float bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq,
                        (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    return check_launch();
+}
+extern "C" int seld_adam_flat_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                    float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                    const uint64_t* state, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state || n < 0) return SELD_EINVAL;
+    if (n == 0) return SELD_OK;
+    hipLaunchKernelGGL(adam_state_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq,
+                       (long long)n, beta1, beta2, eps, weight_decay, grad_scale, state);
+    return check_launch();
+}
+extern "C" int seld_step_begin(float* flat_grad, int64_t n, uint64_t* state, void* stream) {
+    if ((n > 0 && !flat_grad) || n < 0) return SELD_EINVAL;
+    if (n > 0 && ((uintptr_t)flat_grad & 15)) return SELD_EINVAL;
+    hipLaunchKernelGGL(step_begin_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, ST(stream), flat_grad,
+                       (long long)n, state);
     return check_launch();
 }

@@ -17,16 +17,20 @@ namespace seld {
 
 constexpr int FT = 16;
 
+// bin0: first bin kept (1 = DC dropped, the reference's cut_dc=True; 0 = all N/2 + 1 bins), nbins = N/2 + 1 - bin0.
+// window_g (nullable): N window values already divided by their sum; null = periodic Hamming.
 __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, int C, int L, int N, int logN, int hop,
-                                                   int frames_out, int output_phase, float* __restrict__ out) {
+                                                   int frames_out, int output_phase, int bin0,
+                                                   const float* __restrict__ window_g, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int half = N >> 1;
     float2* buf0 = reinterpret_cast<float2*>(smem);                 // N
     float2* buf1 = buf0 + N;                                        // N
     float2* tw = buf1 + N;                                          // N/2
     float* win = reinterpret_cast<float*>(tw + half);               // N
-    float* mag = win + N;                                           // half * (FT + 1)
-    float* pha = mag + half * (FT + 1);                             // half * (FT + 1)
+    const int nbins = half + 1 - bin0;
+    float* mag = win + N;                                           // (half + 1) * (FT + 1)
+    float* pha = mag + (half + 1) * (FT + 1);                       // (half + 1) * (FT + 1)
 
     const int tid = threadIdx.x;
     const int c = blockIdx.y;
@@ -38,7 +42,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, 
         sincospif(-2.0f * (float)j / (float)N, &sn, &cs);
         tw[j] = make_float2(cs, sn);
     }
-    for (int n = tid; n < N; n += blockDim.x) win[n] = (0.54f - 0.46f * cospif(2.0f * (float)n / (float)N)) * inv_wsum;
+    for (int n = tid; n < N; n += blockDim.x)
+        win[n] = window_g ? window_g[n] : (0.54f - 0.46f * cospif(2.0f * (float)n / (float)N)) * inv_wsum;
     __syncthreads();
 
     const float* xc = x + (size_t)c * L;
@@ -69,54 +74,62 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, 
             __syncthreads();
             float2* t = src; src = dst; dst = t;
         }
-        // bins 1 .. N/2 (DC dropped)
-        for (int b = tid; b < half; b += blockDim.x) {
-            const float2 z = src[b + 1];
+        // bins bin0 .. N/2
+        for (int b = tid; b < nbins; b += blockDim.x) {
+            const float2 z = src[b + bin0];
             mag[b * (FT + 1) + f] = sqrtf(z.x * z.x + z.y * z.y);
             if (output_phase) pha[b * (FT + 1) + f] = atan2f(z.y, z.x);
         }
         __syncthreads();
     }
     const int nf = (frames_out - m0) < FT ? (frames_out - m0) : FT;
-    for (int e = tid; e < half * FT; e += blockDim.x) {
+    for (int e = tid; e < nbins * FT; e += blockDim.x) {
         const int b = e / FT, f = e - b * FT;
         if (f < nf) {
-            out[((size_t)c * half + b) * frames_out + m0 + f] = mag[b * (FT + 1) + f];
-            if (output_phase) out[((size_t)(C + c) * half + b) * frames_out + m0 + f] = pha[b * (FT + 1) + f];
+            out[((size_t)c * nbins + b) * frames_out + m0 + f] = mag[b * (FT + 1) + f];
+            if (output_phase) out[((size_t)(C + c) * nbins + b) * frames_out + m0 + f] = pha[b * (FT + 1) + f];
         }
     }
 }
 
-static int frames_after_cut(int L, int N, int noverlap) {
+static int frames_total(int L, int N, int noverlap) {
     const int hop = N - noverlap;
     if (hop <= 0) return -1;
     long long Lp = (long long)L + N;                  // boundary='zeros' extension by N/2 on both sides
     long long nadd = ((-(Lp - N)) % hop + hop) % hop; // padded=True
     nadd %= N;
     long long frames = (Lp + nadd - N) / hop + 1;
-    return (int)(frames - 1);                         // cut_last_timeframe
+    return (int)frames;
 }
 
 }  // namespace seld
 using namespace seld;
 
-extern "C" int seld_stft_frames(int32_t L, int32_t nperseg, int32_t noverlap) {
+extern "C" int seld_stft_frames_ex(int32_t L, int32_t nperseg, int32_t noverlap, int32_t cut_last_timeframe) {
     if (L <= 0 || nperseg <= 1 || noverlap < 0 || noverlap >= nperseg) return SELD_EINVAL;
-    return frames_after_cut(L, nperseg, noverlap);
+    return frames_total(L, nperseg, noverlap) - (cut_last_timeframe ? 1 : 0);
+}
+extern "C" int seld_stft_frames(int32_t L, int32_t nperseg, int32_t noverlap) {
+    return seld_stft_frames_ex(L, nperseg, noverlap, 1);
 }
 
-extern "C" int seld_stft_magphase(const float* x, int32_t C, int32_t L, int32_t nperseg, int32_t noverlap,
-                                  int32_t output_phase, float* out, void* stream) {
+extern "C" int seld_stft_magphase_ex(const float* x, int32_t C, int32_t L, int32_t nperseg, int32_t noverlap,
+                                     int32_t output_phase, int32_t cut_dc, int32_t cut_last_timeframe,
+                                     const float* window, float* out, void* stream) {
     if (!x || !out || C <= 0 || L <= 0 || nperseg <= 1 || noverlap < 0 || noverlap >= nperseg) return SELD_EINVAL;
     int logN = 0;
     while ((1 << logN) < nperseg) ++logN;
     if ((1 << logN) != nperseg || nperseg > 4096 || nperseg < 4) return SELD_EUNSUPPORTED;   // power-of-two segments only
-    const int frames = frames_after_cut(L, nperseg, noverlap);
+    const int frames = frames_total(L, nperseg, noverlap) - (cut_last_timeframe ? 1 : 0);
     if (frames <= 0) return SELD_EINVAL;
     const int half = nperseg / 2;
-    const size_t smem = sizeof(float) * ((size_t)2 * nperseg * 2 + (size_t)half * 2 + nperseg + (size_t)2 * half * (FT + 1));
+    const size_t smem = sizeof(float) * ((size_t)2 * nperseg * 2 + (size_t)half * 2 + nperseg + (size_t)2 * (half + 1) * (FT + 1));
     dim3 grid((frames + FT - 1) / FT, C);
     hipLaunchKernelGGL(stft_kernel, grid, dim3(256), smem, (hipStream_t)stream, x, C, L, nperseg, logN,
-                       nperseg - noverlap, frames, output_phase, out);
+                       nperseg - noverlap, frames, output_phase, cut_dc ? 1 : 0, window, out);
     return check_launch();
+}
+extern "C" int seld_stft_magphase(const float* x, int32_t C, int32_t L, int32_t nperseg, int32_t noverlap,
+                                  int32_t output_phase, float* out, void* stream) {
+    return seld_stft_magphase_ex(x, C, L, nperseg, noverlap, output_phase, 1, 1, nullptr, out, stream);
 }

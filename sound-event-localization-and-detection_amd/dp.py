@@ -90,6 +90,101 @@ class FlatGradSync:
         return 1.0 / world_size()
 
 
+def late_parameters(model):
+    """Parameters whose gradients a backward pass completes LAST: the front-end convolution stages
+    (`ConvTC_Block.cnn`, model.py:261-287) of every branch -- <1 % of the gradient bytes.  Pass them to
+    `FlatAdam(..., late=...)` so that they form the small bucket at the front of the flat gradient buffer."""
+    out = []
+    for m in model.modules():
+        if type(m).__name__ == "ConvTC_Block":
+            out += list(m.cnn.parameters())
+    return out
+
+
+def cut_backward_here(module, x):
+    """Called by a module's forward at the point where a `BackwardCut` splits the backward pass: returns `x` itself when
+    no cut is installed on `module`, else a detached leaf that stands in for it (the pair is remembered for `finish`)."""
+    cuts = getattr(module, "_backward_cuts", None)
+    if cuts is None or not x.requires_grad:
+        return x
+    leaf = x.detach().requires_grad_(True)
+    cuts.append((x, leaf))
+    return leaf
+
+
+class BackwardCut:
+    """Splits the backward pass at the input of every TCN (the output of the front-end convolutions): `loss.backward()`
+    then stops there -- every gradient of the TCN, the attention and the heads is complete and can be exchanged -- and
+    `finish()` runs the rest (the front end), which overlaps that exchange.  The model cooperates through
+    `cut_backward_here` (model.ConvTC_Block.forward calls it on its TCN input)."""
+
+    def __init__(self, model):
+        self.cuts = []
+        self.blocks = [m for m in model.modules() if type(m).__name__ == "ConvTC_Block"]
+        for b in self.blocks:
+            b._backward_cuts = self.cuts
+
+    def reset(self):
+        self.cuts.clear()
+
+    def finish(self):
+        pending = [(a, leaf.grad) for a, leaf in self.cuts if leaf.grad is not None]
+        self.cuts.clear()
+        if pending:
+            torch.autograd.backward([a for a, _ in pending], [g for _, g in pending])
+
+    def remove(self):
+        for b in self.blocks:
+            if getattr(b, "_backward_cuts", None) is self.cuts:
+                del b._backward_cuts
+
+
+class BucketedGradSync:
+    """The data-parallel gradient exchange of a FlatAdam built with `late=late_parameters(model)`: two all-reduces per
+    step over contiguous ranges of the one flat gradient buffer,
+
+        main bucket  flat_grad[late_numel:]   (TCN, attention, heads: > 99 % of the bytes) -- issued asynchronously as
+                                              soon as the backward pass has reached the front-end cut, so it runs on
+                                              RCCL's stream while the front-end convolutions' backward runs on ours;
+        late bucket  flat_grad[:late_numel]   (front-end convolutions) -- issued when the backward pass has ended.
+
+    Each payload is a few MB at most, latency-bound on the xGMI mesh, so neither is split further.  `wait()` makes the
+    compute stream wait for both; the 1/world scale is folded into the Adam kernel (`average_scale`)."""
+
+    def __init__(self, optimizer, model=None, group=None):
+        self.group = group
+        self.flat = optimizer.flat_grad
+        self.late_numel = int(getattr(optimizer, "late_numel", 0))
+        self.world = world_size()
+        self.cut = BackwardCut(model) if (model is not None and self.world > 1 and self.late_numel > 0) else None
+        self._work = []
+
+    def _reduce(self, t):
+        if self.world > 1 and t.numel() > 0:
+            self._work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def reduce_main(self):
+        self._reduce(self.flat[self.late_numel:])
+
+    def reduce_late(self):
+        self._reduce(self.flat[:self.late_numel])
+
+    def all_reduce(self, async_op=False):
+        """Whole buffer at once (no overlap): the round-1 interface."""
+        self.reduce_main()
+        self.reduce_late()
+        if not async_op:
+            self.wait()
+
+    def wait(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+    def average_scale(self):
+        return 1.0 / self.world
+
+
 def broadcast_parameters(module_or_flat, src=0):
     """Make every rank start from rank `src`'s weights (and buffers)."""
     if world_size() == 1:
@@ -118,12 +213,42 @@ def average_bn_running_stats(module):
         off += b.numel()
 
 
+def _join_side_stream():
+    """The accumulating weight-gradient kernels run on hip_ops' side stream: a collective may only read the gradient
+    buffer after the compute stream has joined it."""
+    from . import hip_ops as H
+    H.join_side_stream()
+
+
 def dp_train_step(model, optimizer, sync, x, target, n_sed, loss_fn, sed_weight=1.0, doa_weight=5.0):
-    """One data-parallel step on this rank's shard: zero_grad -> fwd -> loss -> bwd -> all-reduce -> Adam(mean grad)."""
+    """One data-parallel step on this rank's shard (eager; train.GraphedTrainStep is the recorded form):
+    zero_grad -> fwd -> loss -> bwd [-> exchange of the main bucket || bwd of the front end -> exchange of the late
+    bucket] -> Adam(mean gradient)."""
     optimizer.zero_grad()
+    cut = getattr(sync, "cut", None)
+    if cut is not None:
+        cut.reset()
     sed, doa = model(x)
     loss = loss_fn(sed, doa, target, n_sed, sed_weight, doa_weight)
     loss.backward()
-    sync.all_reduce()
+    if x.is_cuda:
+        _join_side_stream()
+    if isinstance(sync, BucketedGradSync):
+        sync.reduce_main()
+        if cut is not None:
+            cut.finish()
+            if x.is_cuda:
+                _join_side_stream()
+        sync.reduce_late()
+        sync.wait()
+    else:
+        sync.all_reduce()
     optimizer.step(grad_scale=sync.average_scale())
     return loss
+
+
+def seed_rank_streams(rank):
+    """Ranks must draw different dropout masks for their different shards (weights stay identical: they are broadcast).
+    Folds the rank into the key of hip_ops' counter-based RNG."""
+    from . import hip_ops as H
+    H.philox.stream_id = int(rank)

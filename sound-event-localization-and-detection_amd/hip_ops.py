@@ -217,7 +217,7 @@ def _direct_targets(params, bias):
 # the element-wise kernels that follow it on the main stream: a 70 us kernel on this GPU spends ~13 us ramping up and
 # draining, which another queue fills (measured: two independent 1x3 convolutions 142 -> 121 us).  The main stream
 # joins the side stream when the backward pass ends (autograd engine callback) and in FlatAdam.step().
-_side = {"stream": None, "dirty": False}
+_side = {"stream": None, "dirty": False, "keep": []}
 
 
 def _side_enabled():
@@ -231,11 +231,16 @@ def join_side_stream():
         ev.record(_side["stream"])
         torch.cuda.current_stream().wait_event(ev)
         _side["dirty"] = False
+    _side["keep"].clear()
 
 
 def _on_side_stream(fn, *tensors):
     """Run `fn` (kernel launches only) on the side stream, ordered after everything already on the current stream.
-    `tensors` are read there: the caching allocator must not recycle them before the side stream is done."""
+    `tensors` are read there: the caching allocator must not recycle them before the side stream is done, and
+    nothing on the main stream may overwrite them before the join.  The second point is about autograd: a backward
+    that hands `dy` on as the gradient of an addend (HyperConvAddFn / HyperConvPairFn) gives the engine a tensor it
+    accumulates into IN PLACE when it holds the only reference -- while the side stream may still be reading it.
+    Holding a reference here until the join makes the engine accumulate out of place instead."""
     if _side["stream"] is None:
         _side["stream"] = torch.cuda.Stream()
     st = _side["stream"]
@@ -247,6 +252,7 @@ def _on_side_stream(fn, *tensors):
     for t in tensors:
         if t is not None:
             t.record_stream(st)
+            _side["keep"].append(t)
     if not _side["dirty"]:
         _side["dirty"] = True
         try:
@@ -750,17 +756,47 @@ def maxpool(x, ph, pw):
 
 
 class _Philox:
-    """Counter-based RNG bookkeeping for the dropout kernels (seed from torch's generator so
-    torch.manual_seed controls it; the offset advances by the number of 128-bit draws)."""
+    """Counter-based RNG bookkeeping for the dropout kernels.  The key is torch's seed (torch.manual_seed controls it)
+    mixed with `stream_id` -- the data-parallel rank, so that ranks draw different masks for their different shards;
+    the counter of a draw is  host offset (advances by the number of 128-bit draws) + device base.
+
+    The device base is word 0 of the per-device STEP STATE (4 x uint64, see seld_step_begin in include/seld_hip.h):
+    it is zero in eager mode; a step recorded as a HIP graph (train.GraphedTrainStep) is captured with host offsets that
+    start at zero and replays with the base advanced by the draws of one step, so every replay sees fresh masks."""
 
     def __init__(self):
         self.offset = 0
+        self.stream_id = 0
+        self._state = {}
 
-    def draw(self, n_groups):
-        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    def seed(self):
+        return (torch.initial_seed() + 0x9E3779B97F4A7C15 * int(self.stream_id)) & 0xFFFFFFFFFFFFFFFF
+
+    def state(self, device):
+        """The step state tensor of `device` (int64[4], uint64 semantics): [philox base, step, lr bits, draws/step]."""
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        t = self._state.get(device)
+        if t is None:
+            t = self._state[device] = torch.zeros(4, device=device, dtype=torch.int64)
+        return t
+
+    def draw(self, n_groups, device):
+        """(seed, offset, step-state tensor) for a kernel that consumes `n_groups` 128-bit draws."""
         off = self.offset
         self.offset += int(n_groups)
-        return seed, off
+        return self.seed(), off, self.state(device)
+
+    def get_offset(self):
+        """Absolute position in the stream (checkpointed by train.save_model): host offset + device base."""
+        base = sum(int(t[0].item()) for t in self._state.values())
+        return self.offset + base
+
+    def set_offset(self, offset):
+        self.offset = int(offset)
+        for t in self._state.values():
+            t[0] = 0
 
 
 philox = _Philox()
@@ -771,21 +807,22 @@ class DropoutFn(torch.autograd.Function):
     def forward(ctx, x, p):
         x = _req(x, "x")
         n = x.numel()
-        seed, off = philox.draw((n + 3) // 4)
+        seed, off, state = philox.draw((n + 3) // 4, x.device)
         y = torch.empty_like(x)
         L.check(L.lib().seld_dropout_fwd(L.ptr(x), ctypes.c_int64(n), ctypes.c_float(p), ctypes.c_uint64(seed),
-                                         ctypes.c_uint64(off), L.ptr(y), L.current_stream()), "seld_dropout_fwd")
-        ctx.rng = (p, seed, off)
+                                         ctypes.c_uint64(off), L.ptr(state), L.ptr(y), L.current_stream()),
+                "seld_dropout_fwd")
+        ctx.rng = (p, seed, off, state)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        p, seed, off = ctx.rng
+        p, seed, off, state = ctx.rng
         dy = _req(dy, "dy")
         dx = torch.empty_like(dy)
         L.check(L.lib().seld_dropout_fwd(L.ptr(dy), ctypes.c_int64(dy.numel()), ctypes.c_float(p),
-                                         ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(dx), L.current_stream()),
-                "seld_dropout_fwd")
+                                         ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(state), L.ptr(dx),
+                                         L.current_stream()), "seld_dropout_fwd")
         return dx, None
 
 
@@ -798,10 +835,10 @@ def dropout(x, p, training):
 def channel_dropout_mask(N, C, p, device):
     """Dropout1d decision per (n, c) row, already scaled by 1/(1-p) (model.py:96-97,127-128)."""
     rows = N * C
-    seed, off = philox.draw((rows + 3) // 4)
+    seed, off, state = philox.draw((rows + 3) // 4, device)
     mask = torch.empty(rows, device=device, dtype=torch.float32)
     L.check(L.lib().seld_dropout_mask_rows(ctypes.c_int64(rows), ctypes.c_float(p), ctypes.c_uint64(seed),
-                                           ctypes.c_uint64(off), L.ptr(mask), L.current_stream()),
+                                           ctypes.c_uint64(off), L.ptr(state), L.ptr(mask), L.current_stream()),
             "seld_dropout_mask_rows")
     return mask
 
@@ -985,6 +1022,21 @@ def adam_flat_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-4, beta1=0.9, b
                                    ctypes.c_int64(param.numel()), ctypes.c_float(lr), ctypes.c_float(beta1),
                                    ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(weight_decay), int(step),
                                    ctypes.c_float(grad_scale), L.current_stream()), "seld_adam_flat")
+
+
+def step_begin(flat_grad, state=None):
+    """Zero the flat gradient buffer and (state given) advance the device-resident step state (seld_step_begin)."""
+    L.check(L.lib().seld_step_begin(L.ptr(flat_grad), ctypes.c_int64(flat_grad.numel()), L.ptr(state), L.current_stream()),
+            "seld_step_begin")
+
+
+def adam_flat_step_state(param, grad, exp_avg, exp_avg_sq, state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                         grad_scale=1.0):
+    """seld_adam_flat with the step number and learning rate taken from the device-resident step state."""
+    L.check(L.lib().seld_adam_flat_state(L.ptr(param), L.ptr(grad), L.ptr(exp_avg), L.ptr(exp_avg_sq),
+                                         ctypes.c_int64(param.numel()), ctypes.c_float(beta1), ctypes.c_float(beta2),
+                                         ctypes.c_float(eps), ctypes.c_float(weight_decay), ctypes.c_float(grad_scale),
+                                         L.ptr(state), L.current_stream()), "seld_adam_flat_state")
 
 
 def stft_magphase(x, nperseg=512, noverlap=128, output_phase=True):

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from .dp import cut_backward_here
 from . import hip_nn as hnn
 from . import hip_ops as H
 from .dual_quaternion.dual_quaternion_layers import *   # noqa: F401,F403
@@ -297,6 +298,9 @@ class ConvTC_Block(nn.Module):
         # relabelling of a contiguous NCHW tensor (channel index c*F' + f)
         B, C, Fp, T = x.shape
         x = x.reshape(B, C * Fp, T)
+        # data-parallel training (dp.BackwardCut): the backward pass can stop here so that the gradients of everything
+        # behind this point are exchanged while the front end's backward pass still runs; a no-op otherwise
+        x = cut_backward_here(self, x)
         x = self.tcn(x)
         return H.transpose12(x)                             # (B, T', V), model.py:318
 

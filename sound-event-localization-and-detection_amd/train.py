@@ -64,43 +64,61 @@ class FlatAdam:
     batch_gate1.*, the last block's conv2_residual) keep a zero gradient, which leaves them unchanged, as
     torch.optim.Adam does by skipping them."""
 
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, late=None):
+        """`late`: parameters whose gradients are the LAST ones a backward pass completes (the front-end convolutions,
+        see dp.late_parameters).  They are stored at the front of the flat buffers, so [0, late_numel) and
+        [late_numel, total) are the two contiguous buckets of the data-parallel exchange (dp.BucketedGradSync: the big
+        bucket is all-reduced while the front end's backward pass is still running).  `self.params`, the state dict
+        and the relative order inside each bucket keep `model.parameters()` order."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdam: no parameters")
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
+        late_ids = {id(p) for p in (late or ())}
+        storage = [p for p in self.params if id(p) in late_ids] + [p for p in self.params if id(p) not in late_ids]
+        self.late_numel = sum(p.numel() for p in self.params if id(p) in late_ids)
         self.flat_param = torch.empty(total, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._offset = {}
         off = 0
         with torch.no_grad():
-            for p in self.params:
+            for p in storage:
                 n = p.numel()
+                self._offset[id(p)] = off
                 self.flat_param[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[off:off + n].view(p.shape)
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
                 p._seld_direct_grad = True      # HIP backward kernels accumulate straight into this view
                 p._seld_owner = self            # ... and may reduce into a slot that is still zero (grad_generation)
                 off += n
+        self.offsets = [self._offset[id(p)] for p in self.params]      # flat offset of params[i]
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=self.params)]
         self.step_count = 0
         self.grad_generation = 0
 
-    def zero_grad(self, set_to_none=False):
-        self.flat_grad.zero_()
+    def zero_grad(self, set_to_none=False, state=None):
+        """`state`: the device-resident step state (hip_ops.philox.state): also advance it (graph-recorded steps)."""
+        if self.flat_grad.is_cuda:
+            H.step_begin(self.flat_grad, state)      # one launch: zero fill (+ step state)
+        else:
+            self.flat_grad.zero_()
         self.grad_generation += 1       # every slot is zero again (hip_ops._claim_grad_slots)
-        off = 0
-        for p in self.params:           # re-attach views if something replaced .grad
-            n = p.numel()
+        for p, off in zip(self.params, self.offsets):           # re-attach views if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
-                p.grad = self.flat_grad[off:off + n].view(p.shape)
-            off += n
+                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, state=None):
+        """`state`: take the step number and the learning rate from the device-resident step state instead of the
+        host's (graph-recorded steps; `sync_from_state` brings the host's count up to date afterwards)."""
         H.join_side_stream()            # weight gradients issued on the side stream (hip_ops._on_side_stream)
         g = self.param_groups[0]
+        if state is not None:
+            H.adam_flat_step_state(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, state, g["betas"][0],
+                                   g["betas"][1], g["eps"], g["weight_decay"], grad_scale)
+            return
         self.step_count += 1
         H.adam_flat_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"],
                          g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], grad_scale)
@@ -113,13 +131,11 @@ class FlatAdam:
         an extra entry is ignored by torch for as long as the parameter has no gradient)."""
         state = {}
         if self.step_count > 0:
-            off = 0
-            for i, p in enumerate(self.params):
+            for i, (p, off) in enumerate(zip(self.params, self.offsets)):
                 n = p.numel()
                 state[i] = dict(step=torch.tensor(float(self.step_count)),
                                 exp_avg=self.exp_avg[off:off + n].view(p.shape).clone(),
                                 exp_avg_sq=self.exp_avg_sq[off:off + n].view(p.shape).clone())
-                off += n
         group = dict(_torch_adam_defaults())
         group.update({k: v for k, v in self.param_groups[0].items() if k != "params"})
         group["params"] = list(range(len(self.params)))
@@ -139,10 +155,7 @@ class FlatAdam:
         index_of = {pid: i for i, pid in enumerate(groups[0]["params"])}
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
-        offsets, off = [], 0
-        for p in self.params:
-            offsets.append(off)
-            off += p.numel()
+        offsets = self.offsets
         steps = set()
         for pid, st in sd["state"].items():
             i = index_of[pid]
@@ -160,6 +173,125 @@ class FlatAdam:
                 self.param_groups[0][k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
         if groups[0].get("amsgrad") or groups[0].get("maximize"):
             raise ValueError("amsgrad / maximize checkpoints are not supported (the reference never sets them)")
+
+
+class GraphedTrainStep:
+    """One training step -- zero_grad -> forward -> BCE + w*MSE -> backward -> [gradient exchange] -> Adam
+    (train.py:552-560) -- recorded ONCE as HIP graphs and replayed: ~400 kernel launches on two streams become one
+    host call, so the step costs what its kernels cost and nothing of the Python / autograd / ctypes time between them
+    (at 16 samples per GPU the eager step is host-bound).  Nothing is traced or compiled: the recorded launches are the
+    same C-ABI calls the eager step makes.
+
+    What a replay must not freeze is kept in device memory and read by the kernels: the Philox base of the dropout
+    masks, the optimiser's step number and the learning rate (the 4-word step state of seld_step_begin).
+
+    Single process: one graph.  Data parallel (`sync` = dp.BucketedGradSync): three graphs with the two collectives
+    issued eagerly between them, so that no collective is ever captured:
+        A  zero_grad, forward, loss, backward down to the front-end cut    -> all-reduce of the big bucket (async)
+        B  backward of the front-end convolutions (overlaps that all-reduce) -> all-reduce of the late bucket
+        C  Adam on the averaged gradients
+    The batch is static: `__call__(x, target)` copies into the recorded input buffers (same shapes)."""
+
+    def __init__(self, model, optimizer, x, target, n_sed, sed_weight=1.0, doa_weight=5.0, sync=None, warmup=2):
+        self.model, self.opt, self.sync = model, optimizer, sync
+        self.n_sed, self.w = n_sed, (float(sed_weight), float(doa_weight))
+        self.x, self.target = x.clone(), target.clone()
+        self.state = H.philox.state(x.device)
+        self.cut = sync.cut if (sync is not None and getattr(sync, "cut", None) is not None and sync.world > 1) else None
+        self._lr = None
+        dev = x.device
+        # eager warm-up on a side stream (allocator pools, kernel modules, host-side caches), as torch recommends
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(max(1, warmup)):
+                self._eager()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        # the step state takes over from the host counters
+        self.state[1] = self.opt.step_count
+        self.state[0] = H.philox.offset
+        self.state[3] = 0
+        H.philox.offset = 0
+        self._push_lr()
+        self.graphs = []
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self.loss = self._phase_a()
+            if self.cut is None:
+                self._phase_b()
+                self._phase_c()
+        self.graphs.append(ga)
+        if self.cut is not None:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                self._phase_b()
+            gc_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gc_, pool=ga.pool()):
+                self._phase_c()
+            self.graphs += [gb, gc_]
+        # the recording itself ran no kernel: undo its host-side bookkeeping, publish the draws per step
+        self.state[3] = H.philox.offset
+        H.philox.offset = 0
+        self.replays = 0
+
+    def _push_lr(self):
+        lr = float(self.opt.param_groups[0]["lr"])
+        if lr != self._lr:
+            self._lr = lr
+            self.state[2] = int(np.float32(lr).view(np.uint32))
+
+    def _eager(self):
+        self.opt.zero_grad()
+        if self.cut is not None:
+            self.cut.reset()
+        sed, doa = self.model(self.x)
+        loss = seld_loss_fn(sed, doa, self.target, self.n_sed, *self.w)
+        loss.backward()
+        if self.cut is not None:
+            self.cut.finish()
+        H.join_side_stream()
+        if self.sync is not None:
+            self.sync.reduce_main()
+            self.sync.reduce_late()
+            self.sync.wait()
+        self.opt.step(grad_scale=self.sync.average_scale() if self.sync is not None else 1.0)
+        return loss
+
+    def _phase_a(self):
+        self.opt.zero_grad(state=self.state)
+        if self.cut is not None:
+            self.cut.reset()
+        sed, doa = self.model(self.x)
+        loss = seld_loss_fn(sed, doa, self.target, self.n_sed, *self.w)
+        loss.backward()
+        H.join_side_stream()
+        return loss.detach()
+
+    def _phase_b(self):
+        if self.cut is not None:
+            self.cut.finish()
+            H.join_side_stream()
+
+    def _phase_c(self):
+        self.opt.step(grad_scale=self.sync.average_scale() if self.sync is not None else 1.0, state=self.state)
+
+    def __call__(self, x=None, target=None):
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+        self._push_lr()
+        self.graphs[0].replay()
+        if self.cut is not None:
+            self.sync.reduce_main()
+            self.graphs[1].replay()
+            self.sync.reduce_late()
+            self.sync.wait()
+            self.graphs[2].replay()
+        self.replays += 1
+        self.opt.step_count += 1
+        return self.loss
 
 
 _ADAM_DEFAULTS = None
@@ -299,8 +431,11 @@ def save_model(model, optimizer, state, path, scheduler=None):
           'state': state}
     if scheduler is not None:
         ck['scheduler_state_dict'] = scheduler.state_dict()
+    # the reference's three RNG states (train.py:40-43, read back by index at :77-80) + a fourth entry it never looks at:
+    # the position of the dropout kernels' counter-based RNG stream, so that a resumed run does not replay masks
     ck['random_states'] = (np.random.get_state(), torch.get_rng_state(),
-                           torch.cuda.get_rng_state() if torch.cuda.is_available() else None)
+                           torch.cuda.get_rng_state() if torch.cuda.is_available() else None,
+                           {'seld_philox_offset': H.philox.get_offset()})
     torch.save(ck, path)
 
 
@@ -322,6 +457,8 @@ def load_model(model, optimizer, path, cuda, device, scheduler=None):
         torch.set_rng_state(rs[1].cpu())
         if torch.cuda.is_available() and rs[2] is not None:
             torch.cuda.set_rng_state(rs[2].cpu())
+    extra = rs[3] if rs is not None and len(rs) > 3 and isinstance(rs[3], dict) else {}
+    H.philox.set_offset(int(extra.get('seld_philox_offset', 0)))     # 0 for checkpoints written by the reference
     return state
 
 
@@ -348,7 +485,9 @@ class CheckpointRotation:
         self.best_epoch_checkpoint = start_epoch
         self.new_best = False
 
-    def end_of_epoch(self, model, optimizer, scheduler, state, epoch, val_loss, extra_files=()):
+    def end_of_epoch(self, model, optimizer, scheduler, state, epoch, val_loss, extra_files=(), periodic_copy=True):
+        """Validation-loss bookkeeping and the per-epoch saves (train.py:588-616).  `periodic_copy=False` leaves the
+        checkpoint_epoch_<E>/ copies to an explicit `periodic_copy()` call after the test leg (what `main` does)."""
         improved = not (val_loss >= state["best_loss"])
         if not improved:
             state["worse_epochs"] += 1
@@ -368,6 +507,14 @@ class CheckpointRotation:
             save_model(model, optimizer, state, self.best_of_checkpoint_path, scheduler)
             self.best_epoch_checkpoint = epoch
         save_model(model, optimizer, state, self.checkpoint_path, scheduler)
+        if periodic_copy:
+            self.periodic_copy(state, epoch, extra_files)
+        return improved
+
+    def periodic_copy(self, state, epoch, extra_files=()):
+        """train.py:671-684: every `checkpoint_step` epochs copy the rotation's files into checkpoint_epoch_<E>/.  The
+        reference does this AFTER the test leg of the same epoch (train.py:623-670), so the copied
+        checkpoint_best_model_on_Test and the `best_test_epoch` in its name are this epoch's."""
         if self.checkpoint_step > 0 and epoch % self.checkpoint_step == 0:
             d = self.model_dir + 'checkpoint_epoch_{}/'.format(epoch)
             os.makedirs(d, exist_ok=True)
@@ -381,7 +528,6 @@ class CheckpointRotation:
             for src, name in copies:
                 if os.path.isfile(src):
                     shutil.copyfile(src, d + name)
-        return improved
 
     def test_checkpoint(self, test_mode):
         """train.py:626-642: which checkpoint the test leg evaluates and the epoch it reports: the best model when this
@@ -594,7 +740,7 @@ def main(args):
             scheduler.step()
         print(f"epoch {epoch}: train {float(train_loss):.5f} val {val_loss:.5f} lr {optimizer.param_groups[0]['lr']:.2e} "
               f"({time.time() - t0:.1f}s)")
-        if rotation.end_of_epoch(model, optimizer, scheduler, state, epoch, val_loss):
+        if rotation.end_of_epoch(model, optimizer, scheduler, state, epoch, val_loss, periodic_copy=False):
             print("MODEL IMPROVED ON VALIDATION SET!")
         if test_data is not None and args.test_step > 0 and epoch % args.test_step == 0:      # train.py:623-670
             path, at_epoch = rotation.test_checkpoint(args.test_mode)
@@ -609,7 +755,10 @@ def main(args):
             if path is not None:
                 # the reference reloads args.load_model here (train.py:667), which only exists when resuming; the live
                 # checkpoint of this epoch is what training must continue from
+                best_test_epoch = state.get("best_test_epoch", 0)
                 state = load_model(model, optimizer, live, args.use_cuda, device, scheduler)
+                state["best_test_epoch"] = best_test_epoch      # set by after_test on the state loaded for the test
+        rotation.periodic_copy(state, epoch)                    # after the test leg, as train.py:671-684
         if args.max_steps and state["step"] >= args.max_steps:
             break
     return state

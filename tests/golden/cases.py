@@ -108,6 +108,37 @@ MODEL_CASES = [
          freq_dim=128, time_dim=512, B=1, train=False, taps=False),
 ]
 
+# ---- config widths with a training step (the 16-wide models above cannot see a kernel variant that is only
+# chosen at 192 / 384 channels).  Short clips (T = 128, B = 2) keep the fp64 reference run and the fixtures small;
+# dropout off as in every parity case; intermediate taps are not stored (taps=False).
+_WIDE = dict(output_classes=14, kernel_size_cnn_blocks=3, pool_size=[[8, 2], [8, 2], [2, 2]], pool_time="TCN", D=[10],
+             dilation_mode="fibonacci", kernel_size_dilated_conv=3, V_kernel_size=3, fc_activations="linear",
+             fc_dropout="Last", class_overlaps=3, use_bias_conv=0, use_bias_linear=1, batch_norm="BN",
+             dropout_perc=0.0, spatial_dropout_rate=0.0, freq_dim=128, time_dim=128, B=2, train=True, taps=False)
+_DQW = dict(_WIDE, domain="DQ", cnn_filters=[192, 192, 192], G=384, U=192, V=[384, 384])
+MODEL_CASES += [
+    # config 3: DQ 8-channel, DQ classifier
+    dict(_DQW, name="c3w_train", domain_classifier="DQ", input_channels=8, fc_layers=[384],
+         full_grads=["seld_block.cnn.0.0.i_weight_2", "seld_block.cnn.1.0.r_weight",
+                     "seld_block.tcn.ResBlocks.5.conv1_filter.j_weight_2", "seld_block.tcn.ResBlocks.9.conv2_skip.k_weight",
+                     "seld_block.tcn.ResBlocks.0.batch_filter2.weight", "sed.0.r_weight_2"]),
+    # config 2: quaternion, real classifier, 64 / 128 widths
+    dict(_WIDE, name="c2w_train", domain="Q", domain_classifier="R", input_channels=8, cnn_filters=[64, 64, 64], G=128,
+         U=64, V=[128, 128], fc_layers=[128],
+         full_grads=["seld_block.cnn.1.0.k_weight", "seld_block.tcn.ResBlocks.4.conv1_gate.i_weight", "doa.0.weight"]),
+    # config 4: 16-channel magnitude + phase input -> the first layer has K = 2 * 9 * 8 = 144 (model.py:273-274 on
+    # config/SERVER_DQSELD-TCN-S1-PHI_16chMagPhase.txt)
+    dict(_DQW, name="c4w_train", domain_classifier="DQ", input_channels=16, fc_layers=[384],
+         full_grads=["seld_block.cnn.0.0.r_weight", "seld_block.cnn.0.0.k_weight_2"]),
+    # config 5: two streams (mic A / mic B magnitude + phase), real classifier with fc 128 (model.py:463-471)
+    dict(_DQW, name="c5w_train", domain_classifier="R", input_channels=16, fc_layers=[128],
+         parallel_ConvTC_block="2Parallel", parallel_magphase=True,
+         full_grads=["branch_A.cnn.0.0.j_weight", "branch_B.tcn.ResBlocks.7.conv2_residual.r_weight_2", "sed.0.weight"]),
+    # config 3 at the config-exact frequency resolution: F = 256 leaves F' = 2, L = 2 * 192 = 384 = U
+    dict(_DQW, name="c3w_F256_train", domain_classifier="DQ", input_channels=8, fc_layers=[384], freq_dim=256, U=384,
+         time_dim=64, full_grads=["seld_block.cnn.2.0.j_weight", "seld_block.tcn.ResBlocks.0.conv1_filter.r_weight"]),
+]
+
 _NON_CTOR = {"name", "B", "train", "taps", "full_grads"}
 
 

@@ -56,6 +56,8 @@ def test_conv_matches_fixture_and_oracle(case, golden):
     (8, (4, 8, 32, 512), 192, (3, 3), 1, 1),    # persistent short-reduction kernel (first CNN layer), 12 channel tiles
     (4, (2, 8, 64, 512), 64, (3, 3), 1, 1),     # same kernel, quaternion model, 4 channel tiles
     (8, (1, 16, 40, 1024), 128, (1, 3), (0, 2), (1, 2)),   # 1x3 dilated, 16-channel input, 8 channel tiles
+    (8, (2, 16, 32, 512), 192, (3, 3), 1, 1),   # config 4 / 5 first layer: 16-channel mag+phase input, K = 144 -> the
+                                                # generic branch of the short-reduction kernel
 ])
 def test_conv_random_vs_oracle(algebra, shape, cout, k, pad, dil):
     import seld_amd
@@ -109,10 +111,10 @@ VEC_CASES = [
 
 
 @pytest.mark.parametrize("algebra,shape,cout,k,pad,dil,cfg", VEC_CASES)
-def test_conv_vec_kernel_vs_oracle(algebra, shape, cout, k, pad, dil, cfg, monkeypatch):
+def test_conv_vec_kernel_vs_oracle(algebra, shape, cout, k, pad, dil, cfg, seld_env):
     import seld_amd
     H = seld_amd.hip_ops
-    monkeypatch.setenv("SELD_CONV_CFG", cfg)
+    seld_env.set("SELD_CONV_CFG", cfg)
     kk = (k,) if isinstance(k, int) else k
     desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
     want = "hc_conv_vec_kernel<" + cfg.replace(",", ", ")
@@ -284,7 +286,7 @@ def test_full_size_adjoint_and_linearity(name, shape, cout, k, pad, dil):
         assert err < 1e-4 * float(y12.abs().max()), err
 
 
-def test_first_layer_kernel_matches_generic_kernel_and_oracle(monkeypatch):
+def test_first_layer_kernel_matches_generic_kernel_and_oracle(seld_env):
     """The persistent short-reduction kernel in its first-layer shape (8 -> 192 channels, 3x3, 64-position tiles in one
     output row, bias folded into the accumulators, BatchNorm statistics in the epilogue) against the generic kernel on
     the same full-size input (bit-level agreement is not expected: different summation order) and against the oracle on
@@ -300,10 +302,10 @@ def test_first_layer_kernel_matches_generic_kernel_and_oracle(monkeypatch):
     desc = H.make_conv_desc(tuple(x.shape), 192, 8, (3, 3), 1, 1, 1)
     stats = H.new_stats(192, torch.device(DEV))
     y = H.conv_fwd(desc, xd, wd, bias=bd, epilogue=L.SELD_EPI_STATS, stats=stats)
-    monkeypatch.setenv("SELD_CONV_NO_SMALLK", "1")
+    seld_env.set("SELD_CONV_NO_SMALLK", "1")
     stats_ref = H.new_stats(192, torch.device(DEV))
     y_ref = H.conv_fwd(desc, xd, wd, bias=bd, epilogue=L.SELD_EPI_STATS, stats=stats_ref)
-    monkeypatch.delenv("SELD_CONV_NO_SMALLK")
+    seld_env.unset("SELD_CONV_NO_SMALLK")
     scale = float(y_ref.abs().max())
     assert float((y - y_ref).abs().max()) <= 1e-5 * scale
     s, sr = stats.view(-1, 2, 192).sum(0), stats_ref.view(-1, 2, 192).sum(0)

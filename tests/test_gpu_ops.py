@@ -275,6 +275,82 @@ def test_stft_matches_fixture_and_oracle(golden):
     assert np.abs(out[:3] - ref[:3]).max() < 1e-5
 
 
+def _check_spectrum(out, ref, C, phase, what):
+    """Magnitude: 2e-6 of the largest magnitude.  Phase: 1e-3 rad (north-star's fp32 tolerance) wherever the bin
+    carries signal, |Z| > 1e-3 * max|Z| -- below that the angle of an fp32 transform is rounding noise."""
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    top = float(np.abs(ref[:C]).max())
+    assert np.abs(out[:C] - ref[:C]).max() < 2e-6 * max(1.0, top) + 2e-7, what
+    if phase:
+        mask = ref[:C] > 1e-3 * top
+        assert mask.mean() > 0.05, what
+        dphi = np.angle(np.exp(1j * (out[C:] - ref[C:])))
+        assert np.abs(dphi[mask]).max() < 1e-3, (what, float(np.abs(dphi[mask]).max()))
+
+
+def test_spectrum_fast_drop_in_matches_reference(golden):
+    """`utility_functions.spectrum_fast` -- the reference's name, arguments and result layout
+    (utility_functions.py:129-155) -- against the reference's own outputs: defaults, magnitude only, and every flag
+    off its default (DC bin kept, last frame kept, another segment length)."""
+    UF = pkg().utility_functions
+    g = golden("stft")
+    n = np.arange(6400)
+    x = np.stack([np.sin(2 * np.pi * (100 + 37 * c) * n / 32000) + 0.1 * np.sin(0.013 * n * (c + 1)) for c in range(8)])
+    out = UF.spectrum_fast(x, nperseg=512, noverlap=112)
+    assert isinstance(out, np.ndarray) and out.dtype == np.float64           # numpy in -> float64 numpy out
+    _check_spectrum(out, g["magphase_112"], 8, True, "defaults, noverlap 112")
+    _check_spectrum(UF.spectrum_fast(x, 512, 112, output_phase=False), g["mag_112"], 8, False, "magnitude only")
+    _check_spectrum(UF.spectrum_fast(x, 512, 128), g["magphase_128"], 8, True, "noverlap 128")
+    _check_spectrum(UF.spectrum_fast(x, nperseg=512, noverlap=128, cut_dc=False, output_phase=True,
+                                     cut_last_timeframe=False), g["magphase_128_dc_last"], 8, True, "dc + last frame kept")
+    _check_spectrum(UF.spectrum_fast(x[:2], nperseg=256, noverlap=56, cut_dc=False, output_phase=False),
+                    g["mag_256_56_dc"], 2, False, "nperseg 256, dc kept")
+    # tensor in -> float32 device tensor out, same values
+    t = UF.spectrum_fast(torch.from_numpy(x).float().to(DEV), 512, 112)
+    assert torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32
+    assert np.array_equal(t.cpu().numpy().astype(np.float64), out)
+    # an explicit window array = scipy's get_window('hamming') reproduces the built-in one
+    w = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(512) / 512)
+    _check_spectrum(UF.spectrum_fast(x, 512, 112, window=w), g["magphase_112"], 8, True, "explicit window")
+    with pytest.raises(ValueError):
+        UF.spectrum_fast(x, 512, 512)
+    with pytest.raises(ValueError):
+        UF.spectrum_fast(x[0], 512, 112)
+
+
+def test_spectrum_fast_full_clip():
+    """The shape of the reference's smoke entry (model.py:555-562): 8 channels x 60 s at 32 kHz -> (16, 256, 4800),
+    checked on a slice of frames against the closed-form oracle, and timed (offline stage; bytes = input + output)."""
+    import time
+    UF = pkg().utility_functions
+    rng = np.random.RandomState(5)
+    L_ = 32000 * 60
+    x = (rng.randn(8, L_) * (0.2 + np.abs(np.sin(np.arange(L_) * 1e-5)))).astype(np.float32)
+    xd = torch.from_numpy(x).to(DEV)
+    out = UF.spectrum_fast(xd, nperseg=512, noverlap=112)
+    assert tuple(out.shape) == (16, 256, 4800)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        out = UF.spectrum_fast(xd, nperseg=512, noverlap=112)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    nbytes = xd.numel() * 4 + out.numel() * 4
+    print(f"spectrum_fast (8, 1920000) -> (16, 256, 4800): {dt * 1e6:.0f} us, {nbytes / dt / 1e9:.0f} GB/s "
+          f"({nbytes / dt / 8e12 * 100:.1f} % of 8 TB/s)")
+    # frames 1000..1063 and the last 40 (which run into the zero padding at the end of the signal) against the oracle
+    # on the matching stretch: a stretch that starts on a hop boundary 2 frames early has its frame j at global frame
+    # f0 - 2 + j, and from j = 1 on no frame touches the stretch's own left zero boundary
+    got = out.cpu().double().numpy()
+    for f0, nf in ((1000, 64), (4760, 40)):
+        s0 = 400 * (f0 - 2)
+        s1 = min(L_, s0 + 400 * (nf + 4) + 512)
+        ref = O.spectrum_fast(x[:, s0:s1].astype(np.float64), 512, 112, output_phase=True, cut_last_timeframe=False)
+        _check_spectrum(np.concatenate((got[:8, :, f0:f0 + nf], got[8:, :, f0:f0 + nf])),
+                        np.concatenate((ref[:8, :, 2:2 + nf], ref[8:, :, 2:2 + nf])), 8, True, f"frames {f0}..{f0 + nf - 1}")
+
+
 @pytest.mark.parametrize("algebra,cin,cout,hw,ph,training", [(8, 8, 192, (16, 64), 8, True), (4, 8, 64, (8, 32), 2, True),
                                                              (8, 8, 64, (16, 96), 8, False)])
 def test_first_stage_fused_backward(algebra, cin, cout, hw, ph, training, monkeypatch):
