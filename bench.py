@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
-    ap.add_argument("--mode", default=os.environ.get("SELD_BENCH_MODE", "graph"), choices=["graph", "eager"])
+    ap.add_argument("--mode", default=os.environ.get("SELD_BENCH_MODE", "eager"), choices=["graph", "eager"])
     ap.add_argument("--roofline-steps", type=int, default=5, help="instrumented eager steps after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")

@@ -259,6 +259,37 @@ int seld_gate_bwd_apply(const float* dy, const float* yf, const float* yg, int32
                         const float* mask, const float* red, int32_t train, float* dyf, float* dyg, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Quaternion / dual-quaternion convolution by the 8-multiplication Hamilton product (csrc/hcq_conv.hip).
+ * Same mathematics as seld_hc_conv_fwd / _bwd_data (quaternion_ops.py:125-147, dual_quaternion_ops.py:111-153):
+ * the bilinear map w (x) x has rank 8, so the convolution is evaluated as 8 real GEMMs of a quarter of the K extent
+ * on sums of two components (3 x 8 = 24 sub-products for the dual quaternion instead of 48) and the results
+ * recombined in the epilogue; fp32 results differ from the block-matrix evaluation by rounding only.
+ * Takes 'same' stride-1 convolutions with 1x1, 1x3 (any dilation) or 3x3 taps, row length a multiple of 64,
+ * algebra 4 or 8, Cout/A a multiple of 16 (dual quaternion also 24).
+ *   seld_hcq_pack_floats  size of the packed weight-form buffer (0: shape not taken, use seld_hc_conv_*)
+ *   seld_hcq_pack         weight forms in MFMA fragment order, once per optimiser step and direction
+ *                         (mode 0 forward, 1 data gradient); npair = 2 packs two convolutions of the same input
+ *                         (conv1_filter | conv1_gate, conv2_skip | conv2_residual, model.py:121-132) for one launch:
+ *                         two outputs (forward) or the sum of the two data gradients (mode 1)
+ *   seld_hcq_conv         y[s] = W_s (x) x [+ bias][+ addend][statistics]  (mode 0), dx = data gradient (mode 1, x = dy)
+ * ------------------------------------------------------------------------------------------ */
+size_t seld_hcq_pack_floats(const seld_conv_desc* desc, int32_t mode, int32_t npair);
+int seld_hcq_pack(const seld_conv_desc* desc, int32_t mode, int32_t npair, const float* const wA[8],
+                  const float* const wB[8], float* wpack, void* stream);
+/* mode 0: y[s] = W_s (x) x for s < npair.  mode 1: y[0] = dgrad(x, W_A) [+ dgrad(x2, W_B) if npair == 2]. */
+int seld_hcq_conv(const seld_conv_desc* desc, int32_t mode, int32_t npair, const float* x, const float* x2,
+                  const float* wpack, float* const y[2], const float* const bias[2], const int32_t epilogue[2],
+                  const float* const addend[2], float* const stats[2], void* stream);
+/* Every layer's weight forms in ONE launch per optimiser step: the caller builds a table of entries
+ * (seld_hcq_pack_entry fills one entry of seld_hcq_pack_entry_bytes() bytes in host memory), copies it to the device
+ * once, and calls seld_hcq_pack_table(table, entries, floats of the largest entry) after every weight update. */
+int seld_hcq_kernel_label(const seld_conv_desc* desc, int32_t mode, int32_t npair, char* buf, int32_t buflen);
+size_t seld_hcq_pack_entry_bytes(void);
+int seld_hcq_pack_entry(const seld_conv_desc* desc, int32_t mode, int32_t npair, const float* const wA[8],
+                        const float* const wB[8], float* wpack, void* entry_host);
+int seld_hcq_pack_table(const void* table_dev, int32_t nentries, int64_t max_floats, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Elementwise / pooling / dropout   (torch.nn.ReLU/Tanh/MaxPool/Dropout at model.py:175-202,
  * 280-282, 449-451)
  * ------------------------------------------------------------------------------------------ */

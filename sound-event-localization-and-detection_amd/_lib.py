@@ -45,9 +45,15 @@ def lib():
     return _lib
 
 
+_reload_hooks = []
+
+
 def reload_env():
-    """Make the library re-read its SELD_* environment switches (it reads them once, at first use)."""
+    """Make the library re-read its SELD_* environment switches (it reads them once, at first use); host-side caches
+    of kernel choices (hip_ops) are dropped with it."""
     check(lib().seld_env_reload(), "seld_env_reload")
+    for fn in _reload_hooks:
+        fn()
 
 
 def check(rc, what):

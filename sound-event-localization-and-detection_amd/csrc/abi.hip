@@ -32,7 +32,7 @@ static void load_env_locked() {
     e.conv_no_smallk = flag("SELD_CONV_NO_SMALLK");
     e.no_fwd_pair = flag("SELD_NO_FWD_PAIR");
     e.conv_pair = flag("SELD_CONV_PAIR");
-    e.conv_no_perm = flag("SELD_CONV_NO_PERM");
+    e.conv_no_hcq = flag("SELD_CONV_NO_HCQ");
     e.wgrad_norow = flag("SELD_WGRAD_NOROW");
     e.wgrad_slow = flag("SELD_WGRAD_SLOW");
     e.mha_no_mfma = flag("SELD_MHA_NO_MFMA");

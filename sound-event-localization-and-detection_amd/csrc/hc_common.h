@@ -24,9 +24,6 @@ struct ConvP {
     int pairing;               // allow primal/dual paired channel tiles (work balance)
     int wt;                    // dgrad: component tensors are transposed to [c][o][k]
     int skip_mode;             // 0 none, 1 (fwd DQ): low-half channels x high-half K is zero, 2 (dgrad DQ): high x low
-    int perm;                  // hc_conv_vec_kernel: channel tile y = primal channels [y*BC/2, (y+1)*BC/2) + the dual
-                               // channels at the same offset, so that EVERY workgroup carries the same share of the
-                               // zero quadrant (contiguous tiles: primal tiles run half the K loop of dual tiles)
     int epilogue;
     WPtrs w;
     const float* wmin;         // lowest component pointer (hc_conv_vec_kernel addresses the others as 32-bit offsets from it)

@@ -125,14 +125,13 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     const bool halves_aligned = (p.skip_mode != 0) && (half_k % KC == 0) && (half_c % 16 == 0);
     // (Pairing primal and dual tiles in one workgroup for balance was measured 0-7 % SLOWER on the TCN layers: the
     // half-K chunks then carry half the MFMAs for the same staging and barrier.  Tiles stay contiguous.)
-    // p.perm: tile y = [y*BC/2, (y+1)*BC/2) of the primal half followed by the same range of the dual half
-    const bool perm = p.perm && halves_aligned && (CT % 2 == 0);
-    const int hb = blockIdx.y * (BC / 2);
-    auto chan_of = [&](int t) __attribute__((always_inline)) {
-        return !perm ? c0 + t : (t < BC / 2 ? hb + t : half_c + hb + (t - BC / 2));
-    };
+    // (Balanced tiles -- every workgroup half primal, half dual channels, so that all run 12 full + 12 half chunks
+    // instead of 12 or 24 full ones -- were measured in round 2: 1x3 forward 67.4 vs 66.7 us, pair data gradient 77.6 vs
+    // 69.4: a chunk costs the same with 36 MFMAs as with 72, the loop is bound by the staging round trip, not by the
+    // matrix pipe.  Tiles stay contiguous.)
+    auto chan_of = [&](int t) __attribute__((always_inline)) { return c0 + t; };
     int kbeg = 0, kend = p.Ktot;
-    if (halves_aligned && !perm) {
+    if (halves_aligned) {
         if (p.skip_mode == 1 && c0 + BC <= half_c) kend = half_k;      // all channels primal
         if (p.skip_mode == 2 && c0 >= half_c) kbeg = half_k;           // all channels dual
     }
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(256) void hc_conv_vec_kernel(const ConvP p) {
     // 16 = return after the setup, 32 = return after staging the first chunk.  On the 1x3 TCN layer (74 us): launch +
     // setup 2.6 us, first load round trip 2.7, first iteration 4.7 (cold), output write-back 4.5, 23 more iterations 2.4 each
     const int nchunks = (p.pairing & 4) ? 1 : (kend - kbeg) / KC;
-    const bool mixed_wg = !(p.pairing & 4) && halves_aligned && (CT % 2 == 0) && (perm || c0 + BC / 2 == half_c);
+    const bool mixed_wg = !(p.pairing & 4) && halves_aligned && (CT % 2 == 0) && (c0 + BC / 2 == half_c);
 
     // ---- X items: everything but the channel advance is loop-invariant ----------------------------------------
     const int quad = tid % QP;
@@ -562,13 +561,7 @@ int hc_conv_vec_try(const ConvP& p_in, int mode, int ct, int pt, hipStream_t st)
     if (hi - lo + comp_bytes >= 0xFFFFFFF0ull) return 0;
     p.wmin = (const float*)lo;
     p.wspan = (unsigned)(hi - lo + comp_bytes);
-    // balanced channel tiles for the dual quaternion (every workgroup: full tile over the shared K half, half tile over
-    // the other): needs the primal / dual boundary on a half-tile boundary and more than one channel tile
-    {
-        const int bc = ct * 16, half_c = p.Cdst / 2, half_k = p.Ktot / 2;
-        p.perm = (!env().conv_no_perm && p.skip_mode != 0 && ct % 2 == 0 && half_c % 16 == 0 && half_k % kc == 0 &&
-                  p.Cdst > bc && half_c % (bc / 2) == 0) ? 1 : 0;
-    }
+
     if (mode == MODE_FWD) {
         if (ct == 12) launch_vec<12, MODE_FWD>(p, st);
         else launch_vec<6, MODE_FWD>(p, st);

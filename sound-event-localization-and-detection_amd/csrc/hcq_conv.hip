@@ -1,0 +1,730 @@
+// Quaternion / dual-quaternion convolution with the 8-multiplication Hamilton product (gfx950), forward and data
+// gradient of the 1-D layers (1x3 dilated, 1x1) and the 3x3 layers.
+//
+// A Hamilton product w (x) x costs 16 real sub-products when it is evaluated as the 4 x 4 block matrix the reference
+// assembles (quaternion_ops.py:131-135).  It is a bilinear map of rank 8: with
+//
+//     P0 = (a3 + a1)(b1 + b2)   P1 = (a0 - a2)(b0 + b3)   P2 = (a0 + a2)(b0 - b3)   P3 = (a3 - a1)(b1 - b2)
+//     P4 = (a3 - a2)(b2 - b3)   P5 = (a1 + a0)(b1 + b0)   P6 = (a0 - a1)(b2 + b3)   P7 = (a3 + a2)(b1 - b0)
+//
+//     c0 = (-P0 + P1 + P2 + P3)/2 + P4      c1 = (-P0 - P1 - P2 + P3)/2 + P5
+//     c2 = ( P0 - P1 + P2 + P3)/2 + P6      c3 = ( P0 + P1 - P2 + P3)/2 - P7
+//
+// (a = weight components r,i,j,k; b = input components; c = output components; the a's always stand on the left, so
+// the identities hold for matrix-valued components, i.e. for convolutions).  The convolution therefore splits into 8
+// INDEPENDENT real GEMMs  P_m = F_m(W) * G_m(X)  of one quarter of the K extent each -- half the MFMA work of the block
+// matrix -- plus sums of two components on the way in and a signed sum of the eight accumulators on the way out.
+// In fp32 the result differs from the 16-product evaluation by rounding only (measured against fp64 on the TCN layer:
+// 2.5e-7 of max|y| against 1.8e-7 for the 16-product form).  The dual quaternion [[Q, 0], [Q2, Q]] is three such
+// products, y_p = Q x_p,  y_d = Q2 x_p + Q x_d: 24 sub-products instead of 48.
+//
+// Kernel structure (one workgroup = 4 waves = 64 positions x one channel tile, 2 workgroups per CU):
+//   * the weight forms F_m are precomputed ONCE per step by hcq_pack_kernel, already in MFMA B-fragment order
+//     ([chunk][range][k-group pair][m][lane]); a wave reads its fragments with coalesced 8/16-byte loads straight from
+//     L2 -- no LDS, no sign logic, no component switching in the loop;
+//   * the input is staged RAW (no im2col): per K chunk of IBC block channels the 4 / 8 component rows of the tile plus
+//     their halo, [component][channel][64 + 2*dpad] floats, 16-byte aligned loads; the taps are offsets into the rows;
+//   * per k-group a lane reads its 4 component values, forms the 8 sums G_m (8 VALU) and issues 8 x tiles MFMAs
+//     (v_mfma_f32_16x16x4_f32) into accumulators indexed [tile][m];
+//   * two K ranges for the dual quaternion: range 0 reads the source half every output needs, range 1 the half only
+//     one half of the outputs needs (the structural zero block is never touched);
+//   * epilogue: the signed sums above, bias / addend / BatchNorm statistics, 16-byte stores.
+#include <string.h>
+#include <type_traits>
+#include "hc_common.h"
+
+namespace seld {
+
+struct HcqP {
+    const float* src;
+    const float* src2;           // data gradient of a pair: dst = dgrad(src, W_0) + dgrad(src2, W_1), the K loop runs over both
+    int nsrc;                    // 1 or 2
+    int mix_ytile;               // index of the channel tile that holds ONLY the mixed 8 + 8 tile (dual quaternion with
+                                 // 24 block channels), or -1
+    const float* wpack;
+    float* dst[2];               // per weight set (a pair launch computes two convolutions of the same input)
+    const float* bias[2];
+    const float* addend[2];
+    float* stats[2];
+    int epilogue[2];
+    int A;                       // 4 or 8
+    int N, Csrc, Cdst;           // channels of src / of ONE dst
+    int IB, OB;                  // Csrc / A, Cdst / A
+    int W;                       // row length (T of a 1-D layer, image width of a 2-D layer)
+    int Himg;                    // image height (1 for 1-D)
+    int dil, dpad;               // dilation along W, padded up to a multiple of 4 (the halo each side of a tile)
+    int wext;                    // 64 + 2 * dpad
+    int nch;                     // K chunks per range (IB / IBC)
+    int half_src[2];             // source half (0 primal, 1 dual) read by range 0 / range 1
+    int ytiles;                  // channel tiles per weight set
+    int ob_step;                 // block channels a channel tile advances by (16, or 0 for the single-tile layout)
+    int tile_half[3][2];         // tile t, 8-channel group g: destination half ...
+    int tile_ob[3][2];           // ... and first block channel (-1: padding, nothing stored); tile 2 = the mixed tile
+    long long range_stride[2];   // floats of one (chunk, range) block of wpack
+    long long ytile_stride;      // floats of one regular channel tile of wpack (all chunks of all sources)
+    long long set_stride;        // floats of one weight set (regular tiles + the mixed tile's block)
+};
+
+typedef unsigned int uintx4h __attribute__((ext_vector_type(4)));
+
+// X-form m from the 4 component values (see the header)
+__device__ __forceinline__ void xforms(const float b[4], float g[8]) {
+    g[0] = b[1] + b[2];
+    g[1] = b[0] + b[3];
+    g[2] = b[0] - b[3];
+    g[3] = b[1] - b[2];
+    g[4] = b[2] - b[3];
+    g[5] = b[1] + b[0];
+    g[6] = b[2] + b[3];
+    g[7] = b[1] - b[0];
+}
+
+// KH x KW taps (1x1, 1x3, 3x3), IBC block channels per K chunk, NT1 tiles active in range 0 only + NT2 tiles active
+// in both ranges (NR = 1: quaternion, one range), XI staging items per thread.
+// MIX: the launch has one extra channel tile (p.mix_ytile) whose workgroups carry a single tile, active in both ranges,
+// made of 8 channels of each half (descriptor slot 2).
+template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI, bool MIX>
+__global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
+    constexpr int TAPS = KH * KW;
+    constexpr int NT = NT1 + NT2;
+    constexpr int KQ = IBC * TAPS;
+    static_assert(KQ % 4 == 0, "a K chunk is a whole number of k-groups");
+    constexpr int NG = KQ / 4;
+    constexpr int NPAIR = (NG + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int A = p.A;
+    const int ROWS = A * IBC * KH;                    // staged rows per chunk
+    const int wext = p.wext, qw = wext >> 2;
+    const int buf_floats = ROWS * wext;
+
+    // ---- tile position ------------------------------------------------------------------------------------------
+    const long long p0 = (long long)blockIdx.x * 64;  // 64 consecutive positions inside ONE row (W % 64 == 0)
+    const int rows_total = p.N * p.Himg;
+    const int row_g = (int)(p0 / p.W);                // n * Himg + h
+    const int w0 = (int)(p0 - (long long)row_g * p.W);
+    const int n_img = row_g / p.Himg;
+    const int h0 = row_g - n_img * p.Himg;
+    (void)rows_total;
+    const int yt = blockIdx.y;                        // channel tile over all weight sets
+    const int set = yt / p.ytiles;
+    const int ytile = yt - set * p.ytiles;
+    const bool mix_wg = MIX && ytile == p.mix_ytile;  // workgroup-uniform
+
+    // ---- staging items: (row, quad) of the raw image of a chunk, everything but the chunk advance is invariant ----
+    const long long S = (long long)p.Himg * p.W;
+    const long long src_bytes = (long long)p.N * p.Csrc * S * 4;
+    const unsigned OOB = 0xFFFFFFF0u;
+    __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, src_bytes > (long long)OOB ? OOB : (unsigned)src_bytes, 0x00020000);
+    unsigned xoff[XI];
+    int xlds[XI];
+    const unsigned xadv = (unsigned)((long long)IBC * S * 4);
+    const int total_items = ROWS * qw;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int f = tid + 256 * i;
+        const bool in = f < total_items;
+        const int ff = in ? f : 0;
+        const int row = ff / qw;
+        const int quad = ff - row * qw;
+        // row = (comp * IBC + ibl) * KH + kh
+        const int kh = row % KH;
+        const int ci = row / KH;
+        const int comp = ci / IBC;
+        const int ibl = ci - comp * IBC;
+        const int hh = h0 + (kh - (KH - 1) / 2);
+        const int ww = w0 - p.dpad + 4 * quad;
+        const bool ok = in && (unsigned)hh < (unsigned)p.Himg && (unsigned)ww < (unsigned)p.W;
+        const long long e = (((long long)n_img * p.Csrc + comp * p.IB + ibl) * p.Himg + hh) * p.W + ww;
+        xoff[i] = ok ? (unsigned)(e * 4) : OOB;
+        xlds[i] = in ? ff * 4 : -1;                    // float index of the quad in the LDS image; -1: no store
+    }
+    floatx4 xr[XI];
+    int xchunk = 0;                                    // chunks requested so far
+    auto load_x = [&]() __attribute__((always_inline)) {
+        if (xchunk == p.nch) {                         // second source of a pair: same offsets, other tensor
+            rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src2, 0, src_bytes > (long long)OOB ? OOB : (unsigned)src_bytes,
+                                                     0x00020000);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xoff[i] = xoff[i] == OOB ? OOB : xoff[i] - (unsigned)p.nch * xadv;
+        }
+        ++xchunk;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const uintx4h v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, xoff[i], 0, 0);
+            xr[i][0] = __uint_as_float(v[0]); xr[i][1] = __uint_as_float(v[1]);
+            xr[i][2] = __uint_as_float(v[2]); xr[i][3] = __uint_as_float(v[3]);
+            xoff[i] = xoff[i] == OOB ? OOB : xoff[i] + xadv;
+        }
+    };
+    auto store_x = [&](int buf) __attribute__((always_inline)) {
+        float* b = lds + buf * buf_floats;
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            if (xlds[i] >= 0) *reinterpret_cast<float4*>(b + xlds[i]) = make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
+    };
+
+    // ---- A-operand addresses: k-group g, this lane's k = 4g + fk -> (ibl, kh, kw); component stride = IBC*KH*wext ----
+    int aoff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int kq = 4 * g + fk;
+        const int ibl = kq / TAPS;
+        const int tap = kq - ibl * TAPS;
+        const int kh = tap / KW;
+        const int kw = tap - kh * KW;
+        aoff[g] = (ibl * KH + kh) * wext + p.dpad + wave * 16 + fr + (kw - (KW - 1) / 2) * p.dil;
+    }
+    const int comp_stride = IBC * KH * wext;
+
+    // ---- weight fragments ------------------------------------------------------------------------------------------
+    const float* wbase = p.wpack + (long long)set * p.set_stride + (long long)ytile * p.ytile_stride;
+    const long long chunk_stride = p.range_stride[0] + (NR > 1 ? p.range_stride[1] : 0);
+
+    floatx4 acc[NT][8];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[t][m] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    // one range of one chunk: NTR tiles starting at tile T0
+    auto run_range = [&](const float* xs, const float* wr, auto t0c, auto ntrc) __attribute__((always_inline)) {
+        constexpr int T0 = decltype(t0c)::value, NTR = decltype(ntrc)::value;
+        // per (pair, m): lane holds NTR x {group 2j, group 2j+1}
+        float2 bcur[8][NTR], bnxt[8][NTR];
+        auto load_b = [&](int j, float2 (*dst)[NTR]) __attribute__((always_inline)) {
+            const float* q = wr + ((long long)j * 8 * 64 + lane) * (2 * NTR);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int t = 0; t < NTR; ++t)
+                    dst[m][t] = *reinterpret_cast<const float2*>(q + (long long)m * 64 * 2 * NTR + 2 * t);
+        };
+        load_b(0, bcur);
+#pragma unroll
+        for (int j = 0; j < NPAIR; ++j) {
+            if (j + 1 < NPAIR) load_b(j + 1, bnxt);
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int g = 2 * j + gg;
+                if (g < NG) {
+                    float b[4], gm[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = xs[aoff[g] + q * comp_stride];
+                    xforms(b, gm);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+#pragma unroll
+                        for (int t = 0; t < NTR; ++t)
+                            acc[T0 + t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                gm[m], gg ? bcur[m][t].y : bcur[m][t].x, acc[T0 + t][m], 0, 0, 0);
+                }
+            }
+            if (j + 1 < NPAIR) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int t = 0; t < NTR; ++t) bcur[m][t] = bnxt[m][t];
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using INT = std::integral_constant<int, NT>;
+    using INT1 = std::integral_constant<int, NT1>;
+    using INT2 = std::integral_constant<int, NT2>;
+
+    // ---- K loop ------------------------------------------------------------------------------------------------
+    using I1 = std::integral_constant<int, 1>;
+    using INTM = std::integral_constant<int, NT1>;      // the mixed tile's accumulators: slot NT1
+    const int nchunks = p.nch * p.nsrc;
+    // the mixed-tile workgroups have their own (smaller) blocks in wpack: one tile in both ranges
+    const long long rs0 = mix_wg ? (long long)NPAIR * 8 * 64 * 2 : p.range_stride[0];
+    const long long cstride = mix_wg ? 2 * rs0 : chunk_stride;
+    load_x();
+    store_x(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) load_x();
+        const float* xb = lds + buf * buf_floats;
+        const float* wc = wbase + (long long)ch * cstride;
+        if (mix_wg) {
+            run_range(xb + p.half_src[0] * 4 * comp_stride, wc, INTM{}, I1{});
+            run_range(xb + p.half_src[1] * 4 * comp_stride, wc + rs0, INTM{}, I1{});
+        } else {
+            run_range(xb + p.half_src[0] * 4 * comp_stride, wc, I0{}, INT{});
+            if (NR > 1) run_range(xb + p.half_src[1] * 4 * comp_stride, wc + p.range_stride[0], INT1{}, INT2{});
+        }
+        if (ch + 1 < nchunks) store_x(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    float* const dst = p.dst[set];
+    const float* const bias = p.bias[set];
+    const float* const addend = p.addend[set];
+    float* const stats = p.stats[set];
+    const int epi = p.epilogue[set];
+    const int grp = fr >> 3;
+    const long long pos_off = (long long)h0 * p.W + w0 + wave * 16 + fk * 4;
+    float* redbuf = lds;                       // the K loop is over (last barrier passed): staging buffers are free
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        // a mixed-tile workgroup holds its one tile in accumulator slot NT1, described by descriptor slot 2
+        const int ds = mix_wg ? 2 : t;
+        const int ob0 = (mix_wg && t != NT1) ? -1 : p.tile_ob[ds][grp];
+        const int half = p.tile_half[ds][grp];
+        const bool chok = ob0 >= 0;
+        const int ob = (chok ? ob0 : 0) + (mix_wg ? 0 : ytile * p.ob_step) + (fr & 7);
+        floatx4 hsum, c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hsum[r] = 0.5f * acc[t][3][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h0_ = 0.5f * acc[t][0][r], h1 = 0.5f * acc[t][1][r], h2 = 0.5f * acc[t][2][r];
+            c[0][r] = (hsum[r] - h0_) + (h1 + h2) + acc[t][4][r];
+            c[1][r] = (hsum[r] - h0_) - (h1 + h2) + acc[t][5][r];
+            c[2][r] = (hsum[r] + h0_) + (h2 - h1) + acc[t][6][r];
+            c[3][r] = (hsum[r] + h0_) + (h1 - h2) - acc[t][7][r];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int chn = (half * 4 + q) * p.OB + ob;           // component-major channel index
+            float s1 = 0.f, s2 = 0.f;
+            if (chok) {
+                const float bv = bias ? bias[chn] : 0.f;
+                const long long off = ((long long)n_img * p.Cdst + chn) * S + pos_off;
+                float4 o = make_float4(c[q][0] + bv, c[q][1] + bv, c[q][2] + bv, c[q][3] + bv);
+                if (epi & SELD_EPI_ADD) {
+                    const float4 ad = *reinterpret_cast<const float4*>(addend + off);
+                    o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                }
+                if (epi & SELD_EPI_ACCUMULATE) {
+                    const float4 old = *reinterpret_cast<const float4*>(dst + off);
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *reinterpret_cast<float4*>(dst + off) = o;
+                s1 = o.x + o.y + o.z + o.w;
+                s2 = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+            }
+            if (epi & SELD_EPI_STATS) {
+                s1 += __shfl_xor(s1, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (fk == 0) {
+                    const int slot = ((wave * NT + t) * 4 + q) * 16 + fr;
+                    redbuf[slot * 2 + 0] = s1;
+                    redbuf[slot * 2 + 1] = s2;
+                }
+            }
+        }
+    }
+    if (epi & SELD_EPI_STATS) {
+        __syncthreads();
+        float* rep = stats + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
+        for (int e = tid; e < NT * 4 * 16; e += 256) {
+            const int fr_ = e & 15, q = (e >> 4) & 3, t = e >> 6;
+            const int g_ = fr_ >> 3;
+            const int ds = mix_wg ? 2 : t;
+            const int ob0 = (mix_wg && t != NT1) ? -1 : p.tile_ob[ds][g_];
+            if (ob0 < 0) continue;
+            const int chn = (p.tile_half[ds][g_] * 4 + q) * p.OB + ob0 + (mix_wg ? 0 : ytile * p.ob_step) + (fr_ & 7);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) {
+                const int slot = ((wv * NT + t) * 4 + q) * 16 + fr_;
+                a1 += redbuf[slot * 2 + 0];
+                a2 += redbuf[slot * 2 + 1];
+            }
+            atomicAdd(rep + chn, a1);
+            atomicAdd(rep + p.Cdst + chn, a2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight forms in fragment order.  One thread per packed float.
+//   mode 0 (forward):        dst block channel = conv output block channel, K runs over (conv input block channel, tap)
+//   mode 1 (data gradient):  dst = conv INPUT block channel, K over (conv output block channel, flipped tap), conjugate
+// Layout: [weight set (forward pairs)] x { regular channel tiles [ytile][source (gradient pairs)][chunk][range][pair]
+// [m][lane][tile][2 groups], then the mixed tile's block [source][chunk][range][pair][m][lane][2 groups] }.
+// ---------------------------------------------------------------------------------------------------------------------
+struct HcqPackP {
+    WPtrs w[2];                  // component tensors (OA, IA, taps) of the 1 or 2 weight sets
+    float* out;
+    int A, mode;
+    int OA, IA, taps;            // of the CONVOLUTION (not swapped for the data gradient)
+    int IBC, nch, NR, NT1, NT2, NG, NPAIR;
+    int half_src[2];
+    int nreg;                    // regular channel tiles per set
+    int has_mix;
+    int nsets;                   // forward pairs: separate outputs
+    int nsrc;                    // gradient pairs: two (source, weight set) along K
+    int ob_step;
+    int tile_half[3][2], tile_ob[3][2];
+    long long range_stride[2], ytile_stride, set_stride, total;
+};
+
+__device__ __forceinline__ float hcq_pack_value(const HcqPackP& p, long long idx) {
+    const int NT = p.NT1 + p.NT2;
+    const int set = (int)(idx / p.set_stride);
+    long long r0 = idx - (long long)set * p.set_stride;
+    const long long reg_total = (long long)p.nreg * p.ytile_stride;
+    const bool mix = r0 >= reg_total;
+    int ytile = 0;
+    long long rs[2];
+    if (mix) {
+        r0 -= reg_total;
+        rs[0] = rs[1] = (long long)p.NPAIR * 8 * 64 * 2;
+    } else {
+        ytile = (int)(r0 / p.ytile_stride);
+        r0 -= (long long)ytile * p.ytile_stride;
+        rs[0] = p.range_stride[0];
+        rs[1] = p.range_stride[1];
+    }
+    const long long chunk_stride = rs[0] + ((p.NR > 1 || mix) ? rs[1] : 0);
+    const int chs = (int)(r0 / chunk_stride);            // chunk over all sources
+    r0 -= (long long)chs * chunk_stride;
+    const int srcsel = chs / p.nch, ch = chs - srcsel * p.nch;
+    const int range = (r0 >= rs[0]) ? 1 : 0;
+    if (range) r0 -= rs[0];
+    const int ntr = mix ? 1 : (range ? p.NT2 : NT);
+    const int per_m = 64 * 2 * ntr;
+    const int per_pair = 8 * per_m;
+    const int j = (int)(r0 / per_pair);
+    int r1 = (int)(r0 - (long long)j * per_pair);
+    const int m = r1 / per_m;
+    r1 -= m * per_m;
+    const int lane = r1 / (2 * ntr);
+    r1 -= lane * 2 * ntr;
+    const int t = r1 >> 1, gg = r1 & 1;
+    const int k = lane >> 4, n = lane & 15;
+    const int g = 2 * j + gg;
+    if (g >= p.NG) return 0.f;
+    const int kq = 4 * g + k;
+    const int ds = mix ? 2 : (range ? p.NT1 + t : t);     // descriptor slot
+    const int grp = n >> 3;
+    const int ob0 = p.tile_ob[ds][grp];
+    if (ob0 < 0) return 0.f;
+    const int dblk = ob0 + (mix ? 0 : ytile * p.ob_step) + (n & 7);     // destination block channel
+    const int kbl = kq / p.taps;
+    const int tap = kq - kbl * p.taps;
+    const int sblk = ch * p.IBC + kbl;                                  // source block channel
+    const int hd = p.tile_half[ds][grp], hs = p.half_src[range];
+    // which quaternion of the dual quaternion couples (source half hs) -> (destination half hd)
+    int qsel = 0;                                                        // 0: Q, 1: Q2, -1: structural zero
+    if (p.A == 8) {
+        if (p.mode == 0) qsel = (hd == hs) ? 0 : (hd == 1 ? 1 : -1);     // y_p = Q x_p; y_d = Q2 x_p + Q x_d
+        else qsel = (hd == hs) ? 0 : (hd == 0 ? 1 : -1);                 // dx_p = Q^ dy_p + Q2^ dy_d; dx_d = Q^ dy_d
+    }
+    if (qsel < 0) return 0.f;
+    const int co = p.mode == 0 ? dblk : sblk;           // conv output / input block channel of the element
+    const int ci = p.mode == 0 ? sblk : dblk;
+    const int tp = p.mode == 0 ? tap : p.taps - 1 - tap;
+    if (co >= p.OA || ci >= p.IA) return 0.f;
+    const size_t e = ((size_t)co * p.IA + ci) * p.taps + tp;
+    const WPtrs& w = p.w[p.mode == 0 ? set : srcsel];
+    float a[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = w.p[qsel * 4 + c][e];
+    if (p.mode == 1) { a[1] = -a[1]; a[2] = -a[2]; a[3] = -a[3]; }      // conjugate
+    switch (m) {
+        case 0: return a[3] + a[1];
+        case 1: return a[0] - a[2];
+        case 2: return a[0] + a[2];
+        case 3: return a[3] - a[1];
+        case 4: return a[3] - a[2];
+        case 5: return a[1] + a[0];
+        case 6: return a[0] - a[1];
+        default: return a[3] + a[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void hcq_pack_kernel(const HcqPackP p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < p.total) p.out[idx] = hcq_pack_value(p, idx);
+}
+
+// Every registered layer in ONE launch (once per optimiser step): blockIdx.y = table entry, blockIdx.x = 256-float
+// block of that entry's buffer.
+__global__ __launch_bounds__(256) void hcq_pack_table_kernel(const HcqPackP* __restrict__ table, int nentries) {
+    const int e = blockIdx.y;
+    if (e >= nentries) return;
+    const HcqPackP& p = table[e];
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long long)gridDim.x * 256)
+        p.out[idx] = hcq_pack_value(p, idx);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+struct HcqPlan {
+    int ok;
+    int KH, KW, IBC, NT1, NT2, NR, XI, mix;
+    HcqP kp;
+    HcqPackP pp;
+    size_t pack_floats;
+    dim3 grid;
+    size_t smem;
+};
+
+// mode 0 forward (npair: 1 or 2 convolutions of the same input -> separate outputs),
+// mode 1 data gradient (npair: 1, or 2 = sum of the gradients of two convolutions w.r.t. their common input).
+static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
+    HcqPlan pl{};
+    const int A = d->algebra;
+    if (A != 4 && A != 8) return pl;
+    if (d->stride[0] != 1 || d->stride[1] != 1 || d->dil[0] != 1) return pl;
+    int o[2];
+    hc_out_shape(d, o);
+    if (o[0] != d->in[0] || o[1] != d->in[1]) return pl;                     // 'same' convolutions only
+    const int KH = d->k[0], KW = d->k[1];
+    if (!((KH == 1 && (KW == 1 || KW == 3)) || (KH == 3 && KW == 3))) return pl;
+    if (2 * d->pad[1] != d->dil[1] * (KW - 1) || 2 * d->pad[0] != (KH - 1)) return pl;
+    if (KW == 1 && d->dil[1] != 1) return pl;
+    const int W = d->in[1], Himg = d->in[0];
+    if (W % 64) return pl;
+    const int Csrc = mode == 0 ? d->Cin : d->Cout, Cdst = mode == 0 ? d->Cout : d->Cin;
+    const int IB = Csrc / A, OB = Cdst / A;
+    if ((long long)d->N * Csrc * Himg * W * 4 >= 0xFFFFFFF0ll) return pl;
+    const int taps = KH * KW;
+    const int nsets = mode == 0 ? npair : 1, nsrc = mode == 1 ? npair : 1;
+    const int dil = KW == 3 ? d->dil[1] : 0;
+    const int dpad = KW == 3 ? (dil + 3) / 4 * 4 : 0;
+    const int wext = 64 + 2 * dpad;
+    // K chunk: candidates in order of preference; two workgroups per CU must fit (78 KB each)
+    static const int cand11[] = {16, 24, 8, 0}, cand13[] = {8, 4, 0}, cand33[] = {4, 0};
+    const int* cand = taps == 1 ? cand11 : (taps == 3 ? cand13 : cand33);
+    int IBC = 0;
+    size_t smem = 0;
+    for (int i = 0; cand[i]; ++i) {
+        if (IB % cand[i]) continue;
+        const int nbuf = (IB / cand[i]) * nsrc > 1 ? 2 : 1;
+        const size_t need = (size_t)nbuf * A * cand[i] * KH * wext * sizeof(float);
+        if (need <= 78 * 1024) { IBC = cand[i]; smem = need; break; }
+    }
+    if (!IBC) return pl;
+    const int rows = A * IBC * KH;
+    const int items = rows * (wext / 4);
+    const int XI = (items + 255) / 256;
+    if (smem < 8 * 1024) smem = 8 * 1024;                                     // statistics scratch of the epilogue
+    // channel tiles
+    HcqP& k = pl.kp;
+    int NT1, NT2, NR, nreg, ob_step, mix = 0;
+    for (int t = 0; t < 3; ++t)
+        for (int g = 0; g < 2; ++g) { k.tile_half[t][g] = 0; k.tile_ob[t][g] = -1; }
+    if (A == 8) {
+        NR = 2;
+        // forward: range 0 = primal source (both destination halves), range 1 = dual source (dual destination only)
+        // gradient: range 0 = dual source (both halves), range 1 = primal source (primal destination only)
+        const int both = mode == 0 ? 1 : 0;           // destination half active in both ranges
+        const int once = 1 - both;
+        k.half_src[0] = mode == 0 ? 0 : 1;
+        k.half_src[1] = 1 - k.half_src[0];
+        if (OB % 16 != 0 && OB % 16 != 8) return pl;
+        NT1 = 1; NT2 = 1; nreg = OB / 16; ob_step = 16;
+        k.tile_half[0][0] = k.tile_half[0][1] = once; k.tile_ob[0][0] = 0; k.tile_ob[0][1] = 8;
+        k.tile_half[1][0] = k.tile_half[1][1] = both; k.tile_ob[1][0] = 0; k.tile_ob[1][1] = 8;
+        if (OB % 16 == 8) {                           // the last 8 block channels of both halves share one tile
+            k.tile_half[2][0] = once; k.tile_ob[2][0] = OB - 8;
+            k.tile_half[2][1] = both; k.tile_ob[2][1] = OB - 8;
+            // 24 block channels: either ONE workgroup per position tile with three tiles (24 accumulators, the input
+            // staged once: cnn.1 949 us against 1139), or the mixed tile in workgroups of its own (twice the
+            // workgroups for layers with few position tiles: TCN data gradient 47.5 us against 68.6)
+            const long long ptiles = (long long)d->N * Himg * W / 64;
+            if (OB == 24 && ptiles >= 512) { NT2 = 2; ob_step = 0; }
+            else mix = 1;
+        }
+        if (nreg == 0) return pl;
+    } else {
+        NR = 1; NT2 = 0;
+        k.half_src[0] = k.half_src[1] = 0;
+        if (OB % 32 == 0) { NT1 = 2; nreg = OB / 32; ob_step = 32; }
+        else if (OB % 16 == 0) { NT1 = 1; nreg = OB / 16; ob_step = 16; }
+        else return pl;
+        for (int t = 0; t < NT1; ++t) { k.tile_ob[t][0] = 16 * t; k.tile_ob[t][1] = 16 * t + 8; }
+    }
+    const int NG = IBC * taps / 4, NPAIR = (NG + 1) / 2;
+    const int NT = NT1 + NT2;
+    k.A = A; k.N = d->N; k.Csrc = Csrc; k.Cdst = Cdst; k.IB = IB; k.OB = OB;
+    k.W = W; k.Himg = Himg; k.dil = dil; k.dpad = dpad; k.wext = wext; k.nch = IB / IBC;
+    k.nsrc = nsrc;
+    k.ytiles = nreg + mix; k.mix_ytile = mix ? nreg : -1; k.ob_step = ob_step;
+    k.range_stride[0] = (long long)NPAIR * 8 * 64 * 2 * NT;
+    k.range_stride[1] = (long long)NPAIR * 8 * 64 * 2 * NT2;
+    k.ytile_stride = (long long)nsrc * k.nch * (k.range_stride[0] + (NR > 1 ? k.range_stride[1] : 0));
+    const long long mix_block = mix ? (long long)nsrc * k.nch * 2 * NPAIR * 8 * 64 * 2 : 0;
+    k.set_stride = (long long)nreg * k.ytile_stride + mix_block;
+    pl.pack_floats = (size_t)k.set_stride * nsets;
+    HcqPackP& q = pl.pp;
+    q.A = A; q.mode = mode; q.OA = d->Cout / A; q.IA = d->Cin / A; q.taps = taps;
+    q.IBC = IBC; q.nch = k.nch; q.NR = NR; q.NT1 = NT1; q.NT2 = NT2; q.NG = NG; q.NPAIR = NPAIR;
+    q.half_src[0] = k.half_src[0]; q.half_src[1] = k.half_src[1];
+    q.nreg = nreg; q.has_mix = mix; q.nsets = nsets; q.nsrc = nsrc; q.ob_step = ob_step;
+    for (int t = 0; t < 3; ++t)
+        for (int g = 0; g < 2; ++g) { q.tile_half[t][g] = k.tile_half[t][g]; q.tile_ob[t][g] = k.tile_ob[t][g]; }
+    q.range_stride[0] = k.range_stride[0]; q.range_stride[1] = k.range_stride[1];
+    q.ytile_stride = k.ytile_stride; q.set_stride = k.set_stride; q.total = (long long)pl.pack_floats;
+    pl.KH = KH; pl.KW = KW; pl.IBC = IBC; pl.NT1 = NT1; pl.NT2 = NT2; pl.NR = NR; pl.XI = XI; pl.mix = mix;
+    const long long ptot = (long long)d->N * Himg * W;
+    pl.grid = dim3((unsigned)(ptot / 64), (unsigned)(k.ytiles * nsets), 1);
+    pl.smem = smem;
+    pl.ok = 1;
+    return pl;
+}
+
+// The instantiation a plan runs: staging items per thread are fixed by (taps, IBC, algebra) except for the dilated 1x3
+// layers (halo width).  Returns 0 if there is none.
+struct HcqKern { int KH, KW, IBC, NT1, NT2, NR, XI, MIX; };
+static int hcq_pick(const HcqPlan& pl, HcqKern* k) {
+    int xi8 = 0, xi4 = 0;
+    if (pl.KH == 1 && pl.KW == 3 && pl.IBC == 8) {
+        xi8 = pl.XI <= 5 ? 5 : (pl.XI <= 7 ? 7 : 9);
+        xi4 = pl.XI <= 3 ? 3 : 5;
+    } else if (pl.KH == 1 && pl.KW == 3 && pl.IBC == 4) { xi8 = 6; xi4 = 3; }
+    else if (pl.KH == 1 && pl.KW == 1 && pl.IBC == 16) { xi8 = 8; xi4 = 4; }
+    else if (pl.KH == 1 && pl.KW == 1 && pl.IBC == 24) { xi8 = 12; xi4 = 6; }
+    else if (pl.KH == 1 && pl.KW == 1 && pl.IBC == 8) { xi8 = 4; xi4 = 2; }
+    else if (pl.KH == 3 && pl.KW == 3 && pl.IBC == 4) { xi8 = 7; xi4 = 4; }
+    else return 0;
+    const int xi = pl.NR == 2 ? xi8 : xi4;
+    if (pl.XI > xi) return 0;
+    *k = HcqKern{pl.KH, pl.KW, pl.IBC, pl.NT1, pl.NT2, pl.NR, xi, pl.mix};
+    return 1;
+}
+
+template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI, bool MIX>
+static int hcq_launch_one(const HcqPlan& pl, hipStream_t st) {
+    auto kern = hcq_conv_kernel<KH, KW, IBC, NT1, NT2, NR, XI, MIX>;
+    if (pl.smem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem) != hipSuccess)
+        return SELD_ELAUNCH;
+    hipLaunchKernelGGL(kern, pl.grid, dim3(256), pl.smem, st, pl.kp);
+    return check_launch();
+}
+
+template <int KH, int KW, int IBC, int XI8, int XI4>
+static int hcq_launch_cfg(const HcqPlan& pl, const HcqKern& k, hipStream_t st) {
+    if (k.NR == 2) {
+        if (k.XI != XI8) return SELD_EUNSUPPORTED;
+        if (k.NT2 == 2) return hcq_launch_one<KH, KW, IBC, 1, 2, 2, XI8, false>(pl, st);
+        return k.MIX ? hcq_launch_one<KH, KW, IBC, 1, 1, 2, XI8, true>(pl, st)
+                     : hcq_launch_one<KH, KW, IBC, 1, 1, 2, XI8, false>(pl, st);
+    }
+    if (k.XI != XI4) return SELD_EUNSUPPORTED;
+    return k.NT1 == 2 ? hcq_launch_one<KH, KW, IBC, 2, 0, 1, XI4, false>(pl, st)
+                      : hcq_launch_one<KH, KW, IBC, 1, 0, 1, XI4, false>(pl, st);
+}
+
+static int hcq_launch(const HcqPlan& pl, hipStream_t st) {
+    HcqKern k;
+    if (!hcq_pick(pl, &k)) return SELD_EUNSUPPORTED;
+    if (k.KW == 3 && k.KH == 1 && k.IBC == 8) {
+        if (k.NR == 2) {
+            if (k.XI == 5) return hcq_launch_cfg<1, 3, 8, 5, 3>(pl, k, st);
+            if (k.XI == 7) return hcq_launch_cfg<1, 3, 8, 7, 3>(pl, k, st);
+            return hcq_launch_cfg<1, 3, 8, 9, 3>(pl, k, st);
+        }
+        if (k.XI == 3) return hcq_launch_cfg<1, 3, 8, 5, 3>(pl, k, st);
+        return hcq_launch_cfg<1, 3, 8, 7, 5>(pl, k, st);
+    }
+    if (k.KH == 1 && k.KW == 3) return hcq_launch_cfg<1, 3, 4, 6, 3>(pl, k, st);
+    if (k.KH == 1 && k.IBC == 16) return hcq_launch_cfg<1, 1, 16, 8, 4>(pl, k, st);
+    if (k.KH == 1 && k.IBC == 24) return hcq_launch_cfg<1, 1, 24, 12, 6>(pl, k, st);
+    if (k.KH == 1 && k.IBC == 8) return hcq_launch_cfg<1, 1, 8, 4, 2>(pl, k, st);
+    return hcq_launch_cfg<3, 3, 4, 7, 4>(pl, k, st);
+}
+
+}  // namespace seld
+
+using namespace seld;
+
+extern "C" size_t seld_hcq_pack_floats(const seld_conv_desc* d, int32_t mode, int32_t npair) {
+    if (hc_validate(d) != SELD_OK || (mode != 0 && mode != 1) || npair < 1 || npair > 2) return 0;
+    if (env().conv_no_hcq) return 0;
+    const HcqPlan pl = hcq_plan(d, mode, npair);
+    HcqKern k;
+    return (pl.ok && hcq_pick(pl, &k)) ? pl.pack_floats : 0;
+}
+
+extern "C" size_t seld_hcq_pack_entry_bytes(void) { return sizeof(HcqPackP); }
+
+/* Kernel symbol (as rocprofv3 prints it) that seld_hcq_conv launches for (desc, mode, npair). */
+extern "C" int seld_hcq_kernel_label(const seld_conv_desc* d, int32_t mode, int32_t npair, char* buf, int32_t buflen) {
+    if (hc_validate(d) != SELD_OK || !buf || buflen < 64) return SELD_EINVAL;
+    const HcqPlan pl = hcq_plan(d, mode, npair);
+    HcqKern k;
+    if (!pl.ok || !hcq_pick(pl, &k)) return SELD_EUNSUPPORTED;
+    snprintf(buf, buflen, "hcq_conv_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", k.KH, k.KW, k.IBC, k.NT1, k.NT2, k.NR, k.XI,
+             k.MIX ? "true" : "false");
+    return SELD_OK;
+}
+
+/* Fill one table entry (host memory, seld_hcq_pack_entry_bytes() bytes) for seld_hcq_pack_table. */
+extern "C" int seld_hcq_pack_entry(const seld_conv_desc* d, int32_t mode, int32_t npair, const float* const wA[8],
+                                   const float* const wB[8], float* wpack, void* entry) {
+    if (hc_validate(d) != SELD_OK || !wA || !wpack || !entry) return SELD_EINVAL;
+    if ((mode != 0 && mode != 1) || npair < 1 || npair > 2 || (npair == 2 && !wB)) return SELD_EINVAL;
+    HcqPlan pl = hcq_plan(d, mode, npair);
+    if (!pl.ok) return SELD_EUNSUPPORTED;
+    for (int i = 0; i < 8; ++i) {
+        pl.pp.w[0].p[i] = i < d->algebra ? wA[i] : nullptr;
+        pl.pp.w[1].p[i] = (npair == 2 && i < d->algebra) ? wB[i] : nullptr;
+    }
+    pl.pp.out = wpack;
+    memcpy(entry, &pl.pp, sizeof(HcqPackP));
+    return SELD_OK;
+}
+
+extern "C" int seld_hcq_pack(const seld_conv_desc* d, int32_t mode, int32_t npair, const float* const wA[8],
+                             const float* const wB[8], float* wpack, void* stream) {
+    HcqPackP e;
+    const int rc = seld_hcq_pack_entry(d, mode, npair, wA, wB, wpack, &e);
+    if (rc != SELD_OK) return rc;
+    const unsigned blocks = (unsigned)((e.total + 255) / 256);
+    hipLaunchKernelGGL(hcq_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e);
+    return check_launch();
+}
+
+/* All entries of a DEVICE table in one launch; max_floats = the largest entry's float count. */
+extern "C" int seld_hcq_pack_table(const void* table_dev, int32_t nentries, int64_t max_floats, void* stream) {
+    if (!table_dev || nentries <= 0 || max_floats <= 0) return SELD_EINVAL;
+    long long bx = (max_floats + 255) / 256;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(hcq_pack_table_kernel, dim3((unsigned)bx, (unsigned)nentries), dim3(256), 0, (hipStream_t)stream,
+                       (const HcqPackP*)table_dev, nentries);
+    return check_launch();
+}
+
+extern "C" int seld_hcq_conv(const seld_conv_desc* d, int32_t mode, int32_t npair, const float* x, const float* x2,
+                             const float* wpack, float* const y[2], const float* const bias[2],
+                             const int32_t epilogue[2], const float* const addend[2], float* const stats[2],
+                             void* stream) {
+    if (hc_validate(d) != SELD_OK || !x || !wpack || !y || !y[0]) return SELD_EINVAL;
+    if ((mode != 0 && mode != 1) || npair < 1 || npair > 2) return SELD_EINVAL;
+    if (mode == 1 && npair == 2 && !x2) return SELD_EINVAL;
+    HcqPlan pl = hcq_plan(d, mode, npair);
+    if (!pl.ok) return SELD_EUNSUPPORTED;
+    const int nsets = mode == 0 ? npair : 1;
+    for (int s = 0; s < 2; ++s) {
+        const bool on = s < nsets;
+        pl.kp.dst[s] = on ? y[s] : nullptr;
+        pl.kp.bias[s] = (on && bias) ? bias[s] : nullptr;
+        pl.kp.epilogue[s] = (on && epilogue) ? epilogue[s] : 0;
+        pl.kp.addend[s] = (on && addend) ? addend[s] : nullptr;
+        pl.kp.stats[s] = (on && stats) ? stats[s] : nullptr;
+        if (on && !pl.kp.dst[s]) return SELD_EINVAL;
+        if ((pl.kp.epilogue[s] & SELD_EPI_ADD) && !pl.kp.addend[s]) return SELD_EINVAL;
+        if ((pl.kp.epilogue[s] & SELD_EPI_STATS) && !pl.kp.stats[s]) return SELD_EINVAL;
+    }
+    pl.kp.src = x;
+    pl.kp.src2 = x2;
+    pl.kp.wpack = wpack;
+    return hcq_launch(pl, (hipStream_t)stream);
+}

@@ -191,6 +191,9 @@ def broadcast_parameters(module_or_flat, src=0):
         return
     if torch.is_tensor(module_or_flat):
         dist.broadcast(module_or_flat, src)
+        if module_or_flat.is_cuda:          # parameters are views of this buffer: their packed forms are stale
+            from . import hip_ops as H
+            H.hcq_weights.weights_changed()
         return
     for t in list(module_or_flat.parameters()) + list(module_or_flat.buffers()):
         dist.broadcast(t.data, src)

@@ -62,19 +62,23 @@ _label_cache = {}
 
 
 class _Timed:
-    def __init__(self, desc, which, mult=1, variant=False):
+    def __init__(self, desc, which, mult=1, variant=False, label=None):
         """variant: the launch runs the kernel's other instantiation (pair data gradient, fused first-stage weight
-        gradient): its symbol ends in ', 1>' instead of ', 0>'."""
+        gradient): its symbol ends in ', 1>' instead of ', 0>'.  label: the kernel symbol when the caller knows it
+        (the fast-product kernels)."""
         self.mult = mult
         self.variant = variant or (mult == 2 and which == 1)
+        self.label = label
         self.on = kernel_timer.active
         if self.on and kernel_timer.only is not None:
-            key = (bytes(desc), which)
-            lab = _label_cache.get(key)
+            lab = label
             if lab is None:
-                lab = _label_cache[key] = _label(desc, which)
-            if self.variant and lab.endswith(", 0>"):
-                lab = lab[:-4] + ", 1>"
+                key = (bytes(desc), which)
+                lab = _label_cache.get(key)
+                if lab is None:
+                    lab = _label_cache[key] = _label(desc, which)
+                if self.variant and lab.endswith(", 0>"):
+                    lab = lab[:-4] + ", 1>"
             self.on = lab in kernel_timer.only
         if self.on:
             self.desc, self.which = desc, which
@@ -90,9 +94,11 @@ class _Timed:
         if self.on:
             self.e1.record()
             fl, by = conv_work(self.desc, self.which)
-            lab = _label(self.desc, self.which)
-            if self.variant and lab.endswith(", 0>"):
-                lab = lab[:-4] + ", 1>"
+            lab = self.label
+            if lab is None:
+                lab = _label(self.desc, self.which)
+                if self.variant and lab.endswith(", 0>"):
+                    lab = lab[:-4] + ", 1>"
             kernel_timer.records.append((lab, self.e0, self.e1, fl * self.mult, by * self.mult))
         return False
 
@@ -153,6 +159,11 @@ def conv_fwd(desc, x, ws, bias=None, out=None, epilogue=0, addend=None, stats=No
     bias = _req(bias, "bias")
     o = conv_out_shape(desc)
     y = out if out is not None else torch.empty(_y_shape(desc, o), device=x.device, dtype=torch.float32)
+    wp = hcq_weights.get(desc, 0, ws) if desc.algebra > 1 else None
+    if wp is not None:                      # 8-multiplication Hamilton product (csrc/hcq_conv.hip)
+        with _Timed(desc, 0, label=_hcq_label_cached(desc, 0, 1) if kernel_timer.active else None):
+            hcq_conv(desc, 0, x, wp, (y,), (bias,), (epilogue,), (_req(addend, "addend"),), (stats,))
+        return y
     with _Timed(desc, 0):
         L.check(L.lib().seld_hc_conv_fwd_ex(ctypes.byref(desc), L.ptr(x), L.ptr_array8(ws), L.ptr(bias), L.ptr(y),
                                             ctypes.c_int32(epilogue), L.ptr(_req(addend, "addend")), L.ptr(stats),
@@ -165,6 +176,11 @@ def conv_bwd_data(desc, dy, ws, x_shape, ahead=None):
     dy = _req(dy, "dy")
     dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
     lib = L.lib()
+    wp = hcq_weights.get(desc, 1, ws) if desc.algebra > 1 else None
+    if wp is not None:
+        with _Timed(desc, 1, label=_hcq_label_cached(desc, 1, 1) if kernel_timer.active else None):
+            hcq_conv(desc, 1, dy, wp, (dx,))
+        return dx
     if ahead is not None:
         wt, ev = ahead
         torch.cuda.current_stream().wait_event(ev)
@@ -200,6 +216,26 @@ def conv_bwd_weight(desc, x, dy, w_shape, want_bias, into=None, bias_into=None):
                                                 None, ctypes.c_size_t(0), L.current_stream()),
                 "seld_hc_conv_bwd_weight")
     return dws, dbias
+
+
+_hcq_labels = {}
+
+
+def _hcq_label_cached(desc, mode, npair):
+    key = (bytes(desc), mode, npair)
+    lab = _hcq_labels.get(key)
+    if lab is None:
+        lab = _hcq_labels[key] = hcq_label(desc, mode, npair)
+    return lab
+
+
+def _hcq_ok(desc, mode, npair=1):
+    """Does the fast-product kernel take this (shape, direction)?  (cached; no weights needed)"""
+    key = (bytes(desc), mode, npair, "ok")
+    v = _hcq_labels.get(key)
+    if v is None:
+        v = _hcq_labels[key] = desc.algebra > 1 and hcq_pack_floats(desc, mode, npair) > 0
+    return v
 
 
 def _direct_targets(params, bias):
@@ -265,7 +301,7 @@ def _transpose_ahead(desc, ws):
     """The data gradient's weight re-layout (seld_hc_conv_transpose_weights), issued NOW on the side stream -- i.e. during
     the forward pass, where it overlaps the convolution -- instead of in front of the data-gradient kernel on the critical
     path of the backward pass (47 launches of ~5 us per step).  Returns (workspace tensor, event) or None."""
-    if not _side_enabled() or not torch.is_grad_enabled():
+    if not _side_enabled() or not torch.is_grad_enabled() or _hcq_ok(desc, 1):
         return None
     lib = L.lib()
     lib.seld_hc_conv_bwd_data_workspace.restype = ctypes.c_size_t
@@ -335,6 +371,187 @@ def hyper_conv(x, ws, bias, stride, padding, dilation):
 
 
 # ======================================================================================
+# 8-multiplication Hamilton product kernels (csrc/hcq_conv.hip)
+# ======================================================================================
+def hcq_pack_floats(desc, mode, nsets=1):
+    """Floats of the packed weight-form buffer, 0 if the fast-product kernel does not take this shape."""
+    lib = L.lib()
+    lib.seld_hcq_pack_floats.restype = ctypes.c_size_t
+    return int(lib.seld_hcq_pack_floats(ctypes.byref(desc), int(mode), int(nsets)))
+
+
+class _HcqWeights:
+    """Packed weight forms of every (layer, direction) that runs on the fast-product kernels.
+
+    The forms depend on the weights only, so they are rebuilt when the weights change, not per call:
+      * `weights_changed()` (FlatAdam.step, anything that rewrites parameters behind torch's back) starts a new epoch;
+        the first request of an epoch re-packs EVERY registered entry in one launch (seld_hcq_pack_table);
+      * an in-place edit torch knows about (load_state_dict, an eager optimiser) shows in the tensors' version counters
+        and re-packs just the entry that is asked for;
+      * parameters that moved (Module.to, FlatAdam re-homing them into its flat buffer) are noticed by their pointers.
+    Entries hold weak references: a deleted model drops out at the next full re-pack."""
+
+    def __init__(self):
+        self.entries = {}
+        self.epoch = 0
+        self.packed_epoch = -1
+        self.table = None
+        self.table_dirty = True
+        self.max_floats = 0
+        self._esize = None
+
+    def weights_changed(self):
+        self.epoch += 1
+
+    def reset(self):
+        self.entries.clear()
+        self.table, self.table_dirty, self.packed_epoch = None, True, -1
+
+    class _Entry:
+        __slots__ = ("desc", "mode", "refs", "npair", "nA", "buf", "ptrs", "vers", "epoch", "host")
+
+    @staticmethod
+    def _alive(e):
+        ws = [r() for r in e.refs]
+        return None if any(w is None for w in ws) else ws
+
+    def _fill(self, e, ws):
+        """(Re)build the table entry of `e` from the weights' current addresses."""
+        lib = L.lib()
+        if self._esize is None:
+            lib.seld_hcq_pack_entry_bytes.restype = ctypes.c_size_t
+            self._esize = int(lib.seld_hcq_pack_entry_bytes())
+        host = ctypes.create_string_buffer(self._esize)
+        wsA, wsB = ws[:e.nA], (ws[e.nA:] if e.npair == 2 else None)
+        L.check(lib.seld_hcq_pack_entry(ctypes.byref(e.desc), e.mode, e.npair, L.ptr_array8(wsA),
+                                        L.ptr_array8(wsB) if wsB is not None else None, L.ptr(e.buf), host),
+                "seld_hcq_pack_entry")
+        e.host = host.raw
+        e.ptrs = tuple(w.data_ptr() for w in ws)
+        e.vers = None
+        e.epoch = -1
+        self.table_dirty = True
+
+    def _pack_all(self):
+        dead = []
+        for key, e in self.entries.items():
+            if e is None:
+                continue
+            ws = self._alive(e)
+            if ws is None or any(not w.is_cuda for w in ws):
+                dead.append(key)
+            elif tuple(w.data_ptr() for w in ws) != e.ptrs:
+                self._fill(e, ws)
+        for key in dead:
+            del self.entries[key]
+            self.table_dirty = True
+        live = [e for e in self.entries.values() if e is not None]
+        if not live:
+            self.packed_epoch = self.epoch
+            return
+        if self.table_dirty:
+            import numpy as np
+            raw = b"".join(e.host for e in live)
+            self.table = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(live[0].buf.device)
+            self.max_floats = max(e.buf.numel() for e in live)
+            self.table_dirty = False
+        L.check(L.lib().seld_hcq_pack_table(L.ptr(self.table), len(live), ctypes.c_int64(self.max_floats),
+                                            L.current_stream()), "seld_hcq_pack_table")
+        for e in live:
+            e.epoch, e.vers = self.epoch, None
+        self.packed_epoch = self.epoch
+
+    def get(self, desc, mode, wsA, wsB=None):
+        """Packed forms for (desc, mode) of the given component tensors, or None if the shape runs on the 16/48-product
+        kernels.  Fresh with respect to the weights as they are when the returned launch order is reached."""
+        import weakref
+        ws = list(wsA) + (list(wsB) if wsB is not None else [])
+        key = (bytes(desc), mode, tuple(id(w) for w in ws))
+        e = self.entries.get(key, 0)
+        if e is None:
+            return None
+        if e == 0 or self._alive(e) is None:
+            npair = 2 if wsB is not None else 1
+            n = hcq_pack_floats(desc, mode, npair) if all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+                                                          for w in ws) else 0
+            if n == 0:
+                self.entries[key] = None
+                return None
+            e = self._Entry()
+            e.desc = L.ConvDesc.from_buffer_copy(bytes(desc))
+            e.mode, e.npair, e.nA = int(mode), npair, len(wsA)
+            e.refs = [weakref.ref(w) for w in ws]
+            e.buf = torch.empty(n, device=ws[0].device, dtype=torch.float32)
+            self._fill(e, ws)
+            self.entries[key] = e
+        ptrs = tuple(w.data_ptr() for w in ws)
+        if ptrs != e.ptrs:
+            self._fill(e, ws)
+        if self.packed_epoch != self.epoch:
+            self._pack_all()
+        vers = tuple(w._version for w in ws)
+        if e.epoch != self.epoch or (e.vers is not None and e.vers != vers):
+            wsA_, wsB_ = ws[:e.nA], (ws[e.nA:] if e.npair == 2 else None)
+            hcq_pack(desc, mode, wsA_, wsB_, out=e.buf)
+            e.epoch = self.epoch
+        e.vers = vers
+        return e.buf
+
+
+hcq_weights = _HcqWeights()
+
+
+def _drop_kernel_choice_caches():
+    hcq_weights.reset()
+    _hcq_labels.clear()
+    _label_cache.clear()
+    _pair_ok_cache.clear()
+
+
+L._reload_hooks.append(_drop_kernel_choice_caches)
+
+
+def hcq_label(desc, mode, npair=1):
+    buf = ctypes.create_string_buffer(96)
+    L.check(L.lib().seld_hcq_kernel_label(ctypes.byref(desc), int(mode), int(npair), buf, 96), "seld_hcq_kernel_label")
+    return buf.value.decode()
+
+
+def hcq_pack(desc, mode, wsA, wsB=None, out=None):
+    """Weight forms F_m(W) in MFMA fragment order (seld_hcq_pack): mode 0 forward, 1 data gradient."""
+    nsets = 2 if wsB is not None else 1
+    n = hcq_pack_floats(desc, mode, nsets)
+    if n == 0:
+        return None
+    if out is None:
+        out = torch.empty(n, device=wsA[0].device, dtype=torch.float32)
+    L.check(L.lib().seld_hcq_pack(ctypes.byref(desc), int(mode), nsets, L.ptr_array8([_req(w, "w") for w in wsA]),
+                                  L.ptr_array8([_req(w, "w") for w in wsB]) if wsB is not None else None, L.ptr(out),
+                                  L.current_stream()), "seld_hcq_pack")
+    return out
+
+
+def _ptr2(a, b=None):
+    arr = (ctypes.c_void_p * 2)()
+    arr[0] = a.data_ptr() if a is not None else 0
+    arr[1] = b.data_ptr() if b is not None else 0
+    return arr
+
+
+def hcq_conv(desc, mode, x, wpack, outs, biases=(None, None), epilogues=(0, 0), addends=(None, None), stats=(None, None),
+             x2=None):
+    """Convolution (mode 0; one or two weight sets -> outs) or data gradient (mode 1; with x2: the sum of the data
+    gradients of two convolutions of the same input) from packed weight forms."""
+    npair = len(outs) if mode == 0 else (2 if x2 is not None else 1)
+    epi = (ctypes.c_int32 * 2)(int(epilogues[0]), int(epilogues[1]) if len(outs) > 1 else 0)
+    pad = lambda v: (tuple(v) + (None, None))[:2]
+    L.check(L.lib().seld_hcq_conv(ctypes.byref(desc), int(mode), npair, L.ptr(_req(x, "x")), L.ptr(_req(x2, "x2")),
+                                  L.ptr(wpack), _ptr2(*pad(outs)), _ptr2(*pad(biases)), epi, _ptr2(*pad(addends)),
+                                  _ptr2(*pad(stats)), L.current_stream()), "seld_hcq_conv")
+    return outs
+
+
+# ======================================================================================
 # conv with fused epilogue (bias / residual add) as an autograd op
 # ======================================================================================
 class HyperConvAddFn(torch.autograd.Function):
@@ -397,21 +614,27 @@ class HyperConvPairFn(torch.autograd.Function):
         epiB = (L.SELD_EPI_ADD if addB is not None else 0) | (L.SELD_EPI_STATS if statsB is not None else 0)
         one_launch = all(v == 1 for v in k)          # 1x1 pairs run the pair instantiation of the kernel
         # (issuing the second of two launches on the side stream was measured: 14.69 vs 14.58 ms per step, not kept)
-        with _Timed(desc, 0, 2, one_launch):
-            rc = L.lib().seld_hc_conv_pair_fwd(
-                ctypes.byref(desc), L.ptr(x), L.ptr_array8([_req(w, "w") for w in wsA]),
-                L.ptr_array8([_req(w, "w") for w in wsB]), L.ptr(_req(biasA, "bias")), L.ptr(_req(biasB, "bias")),
-                L.ptr(yA), L.ptr(yB), ctypes.c_int32(epiA), ctypes.c_int32(epiB), L.ptr(_req(addA, "addend")),
-                L.ptr(_req(addB, "addend")), L.ptr(statsA), L.ptr(statsB), L.current_stream())
-        if rc == -4:       # SELD_EUNSUPPORTED: e.g. the two weight sets lie more than 4 GB apart
-            conv_fwd(desc, x, wsA, biasA, out=yA, epilogue=epiA, addend=addA, stats=statsA)
-            conv_fwd(desc, x, wsB, biasB, out=yB, epilogue=epiB, addend=addB, stats=statsB)
+        wp = hcq_weights.get(desc, 0, wsA, wsB) if algebra > 1 else None
+        if wp is not None:                           # both convolutions in one launch of the fast-product kernel
+            with _Timed(desc, 0, 2, label=_hcq_label_cached(desc, 0, 2) if kernel_timer.active else None):
+                hcq_conv(desc, 0, x, wp, (yA, yB), (_req(biasA, "bias"), _req(biasB, "bias")), (epiA, epiB),
+                         (_req(addA, "addend"), _req(addB, "addend")), (statsA, statsB))
         else:
-            L.check(rc, "seld_hc_conv_pair_fwd")
+            with _Timed(desc, 0, 2, one_launch):
+                rc = L.lib().seld_hc_conv_pair_fwd(
+                    ctypes.byref(desc), L.ptr(x), L.ptr_array8([_req(w, "w") for w in wsA]),
+                    L.ptr_array8([_req(w, "w") for w in wsB]), L.ptr(_req(biasA, "bias")), L.ptr(_req(biasB, "bias")),
+                    L.ptr(yA), L.ptr(yB), ctypes.c_int32(epiA), ctypes.c_int32(epiB), L.ptr(_req(addA, "addend")),
+                    L.ptr(_req(addB, "addend")), L.ptr(statsA), L.ptr(statsB), L.current_stream())
+            if rc == -4:       # SELD_EUNSUPPORTED: e.g. the two weight sets lie more than 4 GB apart
+                conv_fwd(desc, x, wsA, biasA, out=yA, epilogue=epiA, addend=addA, stats=statsA)
+                conv_fwd(desc, x, wsB, biasB, out=yB, epilogue=epiB, addend=addB, stats=statsB)
+            else:
+                L.check(rc, "seld_hc_conv_pair_fwd")
         ctx.desc, ctx.algebra = desc, algebra
         ctx.params = (wsA, wsB, biasA, biasB)
         ctx.wt_ahead = None
-        if ctx.needs_input_grad[0] and _pair_ok(desc, 1):
+        if ctx.needs_input_grad[0] and _pair_ok(desc, 1) and not _hcq_ok(desc, 1, 2):
             a_, b_ = _transpose_ahead(desc, wsA), _transpose_ahead(desc, wsB)
             ctx.wt_ahead = (a_, b_) if a_ is not None and b_ is not None else None
         ctx.save_for_backward(x)
@@ -426,7 +649,12 @@ class HyperConvPairFn(torch.autograd.Function):
         lib = L.lib()
         dx = None
         if ctx.needs_input_grad[0]:
-            if _pair_ok(desc, 1) and ctx.wt_ahead is not None:
+            wp = hcq_weights.get(desc, 1, wsA, wsB) if A > 1 else None
+            if wp is not None:                       # sum of both data gradients in one launch
+                dx = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+                with _Timed(desc, 1, 2, label=_hcq_label_cached(desc, 1, 2) if kernel_timer.active else None):
+                    hcq_conv(desc, 1, dyA, wp, (dx,), x2=dyB)
+            elif _pair_ok(desc, 1) and ctx.wt_ahead is not None:
                 (wtA, evA), (wtB, evB) = ctx.wt_ahead
                 dx = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
                 torch.cuda.current_stream().wait_event(evA)

@@ -114,6 +114,7 @@ class FlatAdam:
         """`state`: take the step number and the learning rate from the device-resident step state instead of the
         host's (graph-recorded steps; `sync_from_state` brings the host's count up to date afterwards)."""
         H.join_side_stream()            # weight gradients issued on the side stream (hip_ops._on_side_stream)
+        H.hcq_weights.weights_changed() # the packed weight forms of the fast-product convolutions are stale now
         g = self.param_groups[0]
         if state is not None:
             H.adam_flat_step_state(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, state, g["betas"][0],

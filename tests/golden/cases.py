@@ -114,7 +114,12 @@ MODEL_CASES = [
 _WIDE = dict(output_classes=14, kernel_size_cnn_blocks=3, pool_size=[[8, 2], [8, 2], [2, 2]], pool_time="TCN", D=[10],
              dilation_mode="fibonacci", kernel_size_dilated_conv=3, V_kernel_size=3, fc_activations="linear",
              fc_dropout="Last", class_overlaps=3, use_bias_conv=0, use_bias_linear=1, batch_norm="BN",
-             dropout_perc=0.0, spatial_dropout_rate=0.0, freq_dim=128, time_dim=128, B=2, train=True, taps=False)
+             dropout_perc=0.0, spatial_dropout_rate=0.0, freq_dim=128, time_dim=128, B=2, train=True, taps=False,
+             # weights: the model's own initialisation under np.random.seed(1); torch.manual_seed(1) (train.py:214-221) --
+             # with the closed-form sinusoids a 192 / 384-wide network is degenerate (saturated attention and tanh,
+             # deep-layer gradients ~1e-6 made of cancellation); gradient tolerance: a network this deep amplifies fp32
+             # rounding -- torch's own fp32 CPU run is 0.3-0.5 % of max|g| away from its fp64 run on these cases
+             fill="init", grad_tol=2e-2)
 _DQW = dict(_WIDE, domain="DQ", cnn_filters=[192, 192, 192], G=384, U=192, V=[384, 384])
 MODEL_CASES += [
     # config 3: DQ 8-channel, DQ classifier
@@ -139,7 +144,7 @@ MODEL_CASES += [
          time_dim=64, full_grads=["seld_block.cnn.2.0.j_weight", "seld_block.tcn.ResBlocks.0.conv1_filter.r_weight"]),
 ]
 
-_NON_CTOR = {"name", "B", "train", "taps", "full_grads"}
+_NON_CTOR = {"name", "B", "train", "taps", "full_grads", "fill", "grad_tol"}
 
 
 def model_kwargs(case):

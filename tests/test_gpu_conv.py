@@ -114,6 +114,7 @@ VEC_CASES = [
 def test_conv_vec_kernel_vs_oracle(algebra, shape, cout, k, pad, dil, cfg, seld_env):
     import seld_amd
     H = seld_amd.hip_ops
+    seld_env.set("SELD_CONV_NO_HCQ", "1")        # this test is about the 16/48-product kernel generation
     seld_env.set("SELD_CONV_CFG", cfg)
     kk = (k,) if isinstance(k, int) else k
     desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
@@ -163,12 +164,13 @@ PAIR_CASES = [
 
 
 @pytest.mark.parametrize("algebra,shape,cout,k,pad,dil,adds", PAIR_CASES)
-def test_conv_pair_matches_two_single_calls(algebra, shape, cout, k, pad, dil, adds):
+def test_conv_pair_matches_two_single_calls(algebra, shape, cout, k, pad, dil, adds, seld_env):
     """seld_hc_conv_pair_* (one launch for two convolutions of the same input) against the single entry points
     and, through them, the oracle: outputs, the summed data gradient and both sets of weight gradients."""
     import ctypes
     import seld_amd
     H, L = seld_amd.hip_ops, seld_amd._lib
+    seld_env.set("SELD_CONV_NO_HCQ", "1")        # the 16/48-product generation (test_hcq_* covers the other one)
     kk = (k,) if isinstance(k, int) else k
     desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
     assert H._pair_ok(desc, 0) and H._pair_ok(desc, 2)
@@ -312,3 +314,115 @@ def test_first_layer_kernel_matches_generic_kernel_and_oracle(seld_env):
     assert torch.allclose(s, sr, rtol=1e-4, atol=1e-2)
     ref = O.dual_quaternion_conv(x[:1].double(), *[w.double() for w in ws], bias.double(), 1, 1, 1, 1)
     assert float((y[:1].cpu().double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+# ---- 8-multiplication Hamilton product kernels (csrc/hcq_conv.hip) ------------------------------------------------------
+# Every instantiation family: dual quaternion with 16-aligned block channels, with 24 (mixed 8 + 8 tile in workgroups
+# of its own when there are few position tiles, three tiles per workgroup when there are many), quaternion with one and
+# two tiles; 1x1 / 1x3 / 3x3 taps; every K-chunk size (8 and 4 for 1x3 by halo width, 16 / 24 / 8 for 1x1, 4 for 3x3);
+# halos across image rows and batch items; dilation larger than the tile.
+HCQ_CASES = [
+    # algebra, x shape, cout, k, pad, dil
+    (8, (2, 192, 128), 384, 3, 5, 5),            # TCN filter / gate; data gradient has 24 block channels, few tiles -> split
+    (8, (3, 192, 64), 384, 3, 55, 55),           # halo wider than the tile, K chunk 4
+    (8, (2, 384, 128), 192, 1, 0, 1),            # skip / residual: chunk 16 forward, 24 in the data gradient
+    (8, (2, 192, 128), 128, 1, 0, 1),            # chunk 8 (24 block channels of input, 16 of output)
+    (8, (1, 192, 4, 128), 192, (3, 3), 1, 1),    # 3x3, halo rows, 24 block channels split
+    (8, (9, 192, 8, 512), 192, (3, 3), 1, 1),    # >= 512 position tiles: three tiles per workgroup
+    (8, (2, 128, 3, 64), 128, (3, 3), 1, 1),
+    (4, (2, 64, 128), 128, 3, 2, 2),             # quaternion, two tiles
+    (4, (2, 128, 64), 64, 1, 0, 1),              # one tile
+    (4, (2, 64, 5, 64), 64, (3, 3), 1, 1),
+    (4, (3, 64, 192), 64, 3, 34, 34),
+]
+
+
+@pytest.mark.parametrize("algebra,shape,cout,k,pad,dil", HCQ_CASES)
+def test_hcq_conv_vs_oracle(algebra, shape, cout, k, pad, dil):
+    """Forward, data gradient (through autograd) and the fused epilogues of the fast-product kernels against the
+    fp64 oracle (the reference's block-matrix algorithm), tolerance as every other convolution test."""
+    import seld_amd
+    H, L = seld_amd.hip_ops, seld_amd._lib
+    kk = (k,) if isinstance(k, int) else k
+    desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
+    assert H.hcq_label(desc, 0).startswith("hcq_conv_kernel<") and H.hcq_label(desc, 1).startswith("hcq_conv_kernel<")
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(shape, generator=gen)
+    wshape = (cout // algebra, shape[1] // algebra) + tuple(kk)
+    ws = [torch.randn(wshape, generator=gen) * 0.2 for _ in range(algebra)]
+    bias = torch.randn(cout, generator=gen)
+    dev = torch.device("cuda:0")
+    xd = x.to(dev).requires_grad_(True)
+    wd = [w.to(dev).requires_grad_(True) for w in ws]
+    bd = bias.to(dev).requires_grad_(True)
+    y = H.hyper_conv(xd, wd, bd, 1, pad, dil)
+    cot = torch.randn(y.shape, generator=gen)
+    (y * cot.to(dev)).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in ws]
+    yr = O.hypercomplex_conv(x64, w64, bias.double(), 1, pad, 1, dil, mode="explicit")
+    (yr * cot.double()).sum().backward()
+    _close(y, yr)
+    _close(xd.grad, x64.grad)
+    for a, b in zip(wd, w64):                    # weight gradients (their own kernels) on the same shapes
+        _close(a.grad, b.grad)
+    addend = torch.randn(y.shape, generator=gen).to(dev)
+    stats_rep = H.new_stats(cout, dev)
+    y2 = H.conv_fwd(desc, xd.detach(), [w.detach() for w in wd], bd.detach(),
+                    epilogue=L.SELD_EPI_ADD | L.SELD_EPI_STATS, addend=addend, stats=stats_rep)
+    ref2 = yr.detach() + addend.double().cpu()
+    _close(y2, ref2)
+    stats = stats_rep.view(H.STATS_REPLICAS, 2 * cout).sum(0).double().cpu()
+    red = tuple(i for i in range(ref2.dim()) if i != 1)
+    assert torch.allclose(stats[:cout], ref2.sum(dim=red), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(stats[cout:], (ref2 ** 2).sum(dim=red), rtol=1e-4, atol=2e-3)
+    # y += conv(x)
+    y3 = y2.clone()
+    H.conv_fwd(desc, xd.detach(), [w.detach() for w in wd], None, out=y3, epilogue=L.SELD_EPI_ACCUMULATE)
+    _close(y3, ref2 + (yr.detach() - bias.double().view(1, -1, *([1] * (yr.dim() - 2)))))
+
+
+@pytest.mark.parametrize("algebra,shape,cout,k,pad,dil", [c for c in HCQ_CASES if c[0] == 8][:5] + [HCQ_CASES[7], HCQ_CASES[8]])
+def test_hcq_pair_matches_two_single_calls(algebra, shape, cout, k, pad, dil):
+    """Two convolutions of one input in one launch (forward) and the sum of their data gradients in one launch, on the
+    fast-product kernels, against the two single calls; replaying the step after an in-place weight edit must pick up
+    the new weights (packed-form cache)."""
+    import seld_amd
+    H = seld_amd.hip_ops
+    kk = (k,) if isinstance(k, int) else k
+    desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
+    assert H._hcq_ok(desc, 0, 2) and H._hcq_ok(desc, 1, 2)
+    gen = torch.Generator().manual_seed(5)
+    dev = torch.device("cuda:0")
+    wshape = (cout // algebra, shape[1] // algebra) + tuple(kk)
+    x = torch.randn(shape, generator=gen).to(dev)
+    wl = [[(torch.randn(wshape, generator=gen) * 0.2).to(dev).requires_grad_(True) for _ in range(algebra)] for _ in range(2)]
+    y_shape = H.conv_fwd(desc, x, [w.detach() for w in wl[0]]).shape
+    adds = [torch.randn(y_shape, generator=gen).to(dev), None]
+    cots = [torch.randn(y_shape, generator=gen).to(dev) for _ in range(2)]
+    stats = [H.new_stats(cout, dev), H.new_stats(cout, dev)]
+
+    def run(pair):
+        xs = x.clone().requires_grad_(True)
+        if pair:
+            ya, yb = H.hyper_conv_pair(xs, wl[0], None, wl[1], None, 1, pad, dil, adds[0], adds[1], stats[0], stats[1])
+        else:
+            ya = H.hyper_conv_add(xs, wl[0], None, adds[0], 1, pad, dil)
+            yb = H.hyper_conv(xs, wl[1], None, 1, pad, dil)
+        ((ya * cots[0]).sum() + (yb * cots[1]).sum()).backward()
+        return ya.detach(), yb.detach(), xs.grad
+
+    for attempt in range(2):
+        for s_ in stats:
+            s_.zero_()
+        got, ref = run(True), run(False)
+        for a, b in zip(got, ref):
+            _close(a, b)
+        red = tuple(i for i in range(ref[0].dim()) if i != 1)
+        for s_, r in zip(stats, ref[:2]):
+            tot = s_.view(H.STATS_REPLICAS, 2 * cout).sum(0)
+            assert torch.allclose(tot[:cout], r.sum(dim=red), rtol=1e-4, atol=2e-3)
+        with torch.no_grad():                       # edit the weights in place: the packed forms must follow
+            for w in wl[0] + wl[1]:
+                w.mul_(-0.5).add_(0.01)
+                w.grad = None

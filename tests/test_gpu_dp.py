@@ -105,7 +105,7 @@ def test_two_rank_graphed_step_matches_eager(tmp_path):
     g0, g1 = _run_ranks(tmp_path / "g", "tiny_DQ", "graph", 3)       # + 1 warm-up step inside the constructor
     assert torch.equal(g0["param"], g1["param"])
     assert g0["step_count"] == 4 and int(g0["state"][1]) == 4
-    assert np.allclose(g0["losses"], e0["losses"][1:], rtol=2e-4)
+    assert np.allclose(g0["losses"], e0["losses"][1:], rtol=3e-3) and abs(g0["losses"][0] - e0["losses"][1]) <= 2e-4 * e0["losses"][1]
     # Parameters: Adam normalises every element's step to ~lr, so elements whose gradient is float-atomic ordering noise
     # move by up to lr per step in either run (tests/test_gpu_model.py::test_six_step_trajectory has the calibration);
     # the mean deviation is what shows a wrong exchange
@@ -150,7 +150,9 @@ def test_graphed_step_matches_eager_step():
     statistics and num_batches_tracked; Adam's bias correction follows the device-resident step counter."""
     le, pe, sde, _ = _one_process_steps("eager", 5, False)
     lg, pg, sdg, opt = _one_process_steps("graph", 5, False)
-    assert np.allclose(lg, le[1:], rtol=2e-4), (lg, le)
+    # the first steps agree to rounding; later ones can part by ~1e-3 when a float-atomic ordering difference flips
+    # a pooling arg-max (two eager runs do the same: tools/diag_r2.py)
+    assert np.allclose(lg[:3], le[1:4], rtol=2e-4) and np.allclose(lg, le[1:], rtol=3e-3), (lg, le)
     d = (pg - pe).abs()
     assert d.mean().item() <= 0.02 * 1e-3 and d.max().item() <= 5.5e-3, (d.mean().item(), d.max().item())
     assert opt.step_count == 5
@@ -158,7 +160,7 @@ def test_graphed_step_matches_eager_step():
         if k.endswith("num_batches_tracked"):
             assert int(sdg[k]) == int(sde[k]) == 5, k
         elif "running_" in k:
-            assert torch.allclose(sdg[k], sde[k], rtol=1e-4, atol=1e-6), k
+            assert torch.allclose(sdg[k], sde[k], rtol=5e-3, atol=1e-5), k
 
 
 def test_graphed_step_draws_fresh_dropout_masks():

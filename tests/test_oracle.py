@@ -78,9 +78,7 @@ def test_mha_matches_reference(golden):
 def build_state(case, dtype=DT):
     """State dict with the reference's key names/shapes/order, built by the host-side mirror."""
     from tests.helpers import reference_layout_state
-    sd = reference_layout_state(case, dtype)
-    O.closed_form_fill_(list(sd.items()))
-    return sd
+    return reference_layout_state(case, dtype)        # weights filled per case (tests.helpers.fill_weights)
 
 
 @pytest.mark.parametrize("mode", ["assembled", "explicit"])
