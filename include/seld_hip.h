@@ -289,6 +289,17 @@ int seld_hcq_pack_entry(const seld_conv_desc* desc, int32_t mode, int32_t npair,
                         const float* const wB[8], float* wpack, void* entry_host);
 int seld_hcq_pack_table(const void* table_dev, int32_t nentries, int64_t max_floats, void* stream);
 
+/* Weight gradient on the fast product (csrc/hcq_wgrad.hip): dW = sum over positions of dy (x) conj(x) is again a Hamilton
+ * product per (output block channel, input block channel, tap): 8 (24 for the dual quaternion) real sub-products
+ * instead of 16 (48).  dwA[c] += gradient of conv(x; W_A) given dyA; npair == 2: also dwB[c] += that of a second
+ * convolution of the same input given dyB (conv1_filter | conv1_gate, conv2_skip | conv2_residual).  Accumulating (the
+ * caller's buffers are FlatAdam's gradient slices, train.py:557); no bias gradient (use seld_hc_conv_bwd_weight_acc).
+ * seld_hcq_wgrad_supported: 1 if the shape is taken ('same' stride-1 1x1 / 1x3 / 3x3, row length a multiple of 32). */
+int seld_hcq_wgrad_supported(const seld_conv_desc* desc, int32_t npair);
+int seld_hcq_wgrad_label(const seld_conv_desc* desc, int32_t npair, char* buf, int32_t buflen);
+int seld_hcq_wgrad_acc(const seld_conv_desc* desc, int32_t npair, const float* x, const float* dyA, const float* dyB,
+                       float* const dwA[8], float* const dwB[8], void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Elementwise / pooling / dropout   (torch.nn.ReLU/Tanh/MaxPool/Dropout at model.py:175-202,
  * 280-282, 449-451)

@@ -81,9 +81,9 @@ __device__ __forceinline__ void xforms(const float b[4], float g[8]) {
 
 // KH x KW taps (1x1, 1x3, 3x3), IBC block channels per K chunk, NT1 tiles active in range 0 only + NT2 tiles active
 // in both ranges (NR = 1: quaternion, one range), XI staging items per thread.
-// MIX: the launch has one extra channel tile (p.mix_ytile) whose workgroups carry a single tile, active in both ranges,
-// made of 8 channels of each half (descriptor slot 2).
-template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI, bool MIX>
+// The channel tile p.mix_ytile (dual quaternion with 24 block channels, split layout) runs the same program with other
+// descriptors: its range-0-only tile is padding, its both-range tile is descriptor slot 2 (8 channels of each half).
+template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI>
 __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     constexpr int TAPS = KH * KW;
     constexpr int NT = NT1 + NT2;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     const int yt = blockIdx.y;                        // channel tile over all weight sets
     const int set = yt / p.ytiles;
     const int ytile = yt - set * p.ytiles;
-    const bool mix_wg = MIX && ytile == p.mix_ytile;  // workgroup-uniform
+    const bool mix_wg = ytile == p.mix_ytile;         // workgroup-uniform
 
     // ---- staging items: (row, quad) of the raw image of a chunk, everything but the chunk advance is invariant ----
     const long long S = (long long)p.Himg * p.W;
@@ -192,46 +192,39 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc[t][m] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    // one range of one chunk: NTR tiles starting at tile T0
-    auto run_range = [&](const float* xs, const float* wr, auto t0c, auto ntrc) __attribute__((always_inline)) {
+    // ---- one K chunk = range 0's NG k-groups, then range 1's.  Software pipeline, forced with scheduling barriers
+    // (left alone, the compiler sinks every fragment load to just before its MFMA and waits for it there: 43 % MFMA busy):
+    //   * weight fragments come in pairs of k-groups; the pair after the current one (or the next chunk's first pair)
+    //     is requested when the current pair starts, into the other half of a two-stage register buffer;
+    //   * the raw component values of k-group g+1 are read from LDS at the start of group g and turned into the 8 sums
+    //     under the MFMAs of group g, so no VALU result feeds the very next MFMA.
+    float2 bfr[2][8][NT];
+    float gm[2][8];
+    float raw[4];
+    constexpr int NPC = NR * NPAIR;                          // fragment pairs per chunk
+    constexpr bool CARRY = (NPC % 2) == 0;                   // stage parity survives a chunk: prefetch across chunks
+
+    auto load_b = [&](const float* blk, int j, int stage, auto ntrc) __attribute__((always_inline)) {
+        constexpr int NTR = decltype(ntrc)::value;
+        const float* q = blk + ((long long)j * 8 * 64 + lane) * (2 * NTR);
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int t = 0; t < NTR; ++t)
+                bfr[stage][m][t] = *reinterpret_cast<const float2*>(q + (long long)m * 64 * 2 * NTR + 2 * t);
+    };
+    auto read_raw = [&](const float* xs, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[q] = xs[aoff[g] + q * comp_stride];
+    };
+    auto mfma_group = [&](int bstage, int gg, int gstage, auto t0c, auto ntrc) __attribute__((always_inline)) {
         constexpr int T0 = decltype(t0c)::value, NTR = decltype(ntrc)::value;
-        // per (pair, m): lane holds NTR x {group 2j, group 2j+1}
-        float2 bcur[8][NTR], bnxt[8][NTR];
-        auto load_b = [&](int j, float2 (*dst)[NTR]) __attribute__((always_inline)) {
-            const float* q = wr + ((long long)j * 8 * 64 + lane) * (2 * NTR);
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
+        for (int m = 0; m < 8; ++m)
 #pragma unroll
-                for (int t = 0; t < NTR; ++t)
-                    dst[m][t] = *reinterpret_cast<const float2*>(q + (long long)m * 64 * 2 * NTR + 2 * t);
-        };
-        load_b(0, bcur);
-#pragma unroll
-        for (int j = 0; j < NPAIR; ++j) {
-            if (j + 1 < NPAIR) load_b(j + 1, bnxt);
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                const int g = 2 * j + gg;
-                if (g < NG) {
-                    float b[4], gm[8];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b[q] = xs[aoff[g] + q * comp_stride];
-                    xforms(b, gm);
-#pragma unroll
-                    for (int m = 0; m < 8; ++m)
-#pragma unroll
-                        for (int t = 0; t < NTR; ++t)
-                            acc[T0 + t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                gm[m], gg ? bcur[m][t].y : bcur[m][t].x, acc[T0 + t][m], 0, 0, 0);
-                }
-            }
-            if (j + 1 < NPAIR) {
-#pragma unroll
-                for (int m = 0; m < 8; ++m)
-#pragma unroll
-                    for (int t = 0; t < NTR; ++t) bcur[m][t] = bnxt[m][t];
-            }
-        }
+            for (int t = 0; t < NTR; ++t)
+                acc[T0 + t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    gm[gstage][m], gg ? bfr[bstage][m][t].y : bfr[bstage][m][t].x, acc[T0 + t][m], 0, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>;
     using INT = std::integral_constant<int, NT>;
@@ -239,26 +232,47 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     using INT2 = std::integral_constant<int, NT2>;
 
     // ---- K loop ------------------------------------------------------------------------------------------------
-    using I1 = std::integral_constant<int, 1>;
-    using INTM = std::integral_constant<int, NT1>;      // the mixed tile's accumulators: slot NT1
     const int nchunks = p.nch * p.nsrc;
-    // the mixed-tile workgroups have their own (smaller) blocks in wpack: one tile in both ranges
-    const long long rs0 = mix_wg ? (long long)NPAIR * 8 * 64 * 2 : p.range_stride[0];
-    const long long cstride = mix_wg ? 2 * rs0 : chunk_stride;
     load_x();
     store_x(0);
+    load_b(wbase, 0, 0, INT{});
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < nchunks) load_x();
         const float* xb = lds + buf * buf_floats;
-        const float* wc = wbase + (long long)ch * cstride;
-        if (mix_wg) {
-            run_range(xb + p.half_src[0] * 4 * comp_stride, wc, INTM{}, I1{});
-            run_range(xb + p.half_src[1] * 4 * comp_stride, wc + rs0, INTM{}, I1{});
-        } else {
-            run_range(xb + p.half_src[0] * 4 * comp_stride, wc, I0{}, INT{});
-            if (NR > 1) run_range(xb + p.half_src[1] * 4 * comp_stride, wc + p.range_stride[0], INT1{}, INT2{});
+        const float* wc = wbase + (long long)ch * chunk_stride;
+        const float* wn = ch + 1 < nchunks ? wc + chunk_stride : nullptr;
+        const float* xs0 = xb + p.half_src[0] * 4 * comp_stride;
+        const float* xs1 = xb + p.half_src[1] * 4 * comp_stride;
+        if (!CARRY && ch > 0) load_b(wc, 0, 0, INT{});
+        read_raw(xs0, 0);
+        xforms(raw, gm[0]);
+#pragma unroll
+        for (int s = 0; s < NR * NG; ++s) {                   // k-groups of the chunk, both ranges
+            const int r = s / NG, g = s - r * NG;
+            const int pc = r * NPAIR + g / 2;                // fragment pair of this group within the chunk
+            const int bst = pc & 1, gst = s & 1;
+            const bool last = s + 1 == NR * NG;
+            if ((g & 1) == 0) {                               // a new pair starts: request the one after it
+                const int pn = pc + 1;
+                if (pn < NPC) {
+                    const int rn = pn / NPAIR, jn = pn - rn * NPAIR;
+                    if (rn == 0) load_b(wc, jn, bst ^ 1, INT{});
+                    else load_b(wc + p.range_stride[0], jn, bst ^ 1, INT2{});
+                } else if (CARRY && wn) {
+                    load_b(wn, 0, bst ^ 1, INT{});
+                }
+            }
+            if (!last) {
+                const int rn = (s + 1) / NG, gn = (s + 1) - rn * NG;
+                read_raw(rn == 0 ? xs0 : xs1, gn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (r == 0) mfma_group(bst, g & 1, gst, I0{}, INT{});
+            else mfma_group(bst, g & 1, gst, INT1{}, INT2{});
+            if (!last) xforms(raw, gm[gst ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (ch + 1 < nchunks) store_x(buf ^ 1);
         __syncthreads();
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     float* redbuf = lds;                       // the K loop is over (last barrier passed): staging buffers are free
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        // a mixed-tile workgroup holds its one tile in accumulator slot NT1, described by descriptor slot 2
+        // a mixed-tile workgroup: accumulator slot NT1 is descriptor slot 2, the other slots are padding
         const int ds = mix_wg ? 2 : t;
         const int ob0 = (mix_wg && t != NT1) ? -1 : p.tile_ob[ds][grp];
         const int half = p.tile_half[ds][grp];
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
 //   mode 0 (forward):        dst block channel = conv output block channel, K runs over (conv input block channel, tap)
 //   mode 1 (data gradient):  dst = conv INPUT block channel, K over (conv output block channel, flipped tap), conjugate
 // Layout: [weight set (forward pairs)] x { regular channel tiles [ytile][source (gradient pairs)][chunk][range][pair]
-// [m][lane][tile][2 groups], then the mixed tile's block [source][chunk][range][pair][m][lane][2 groups] }.
+// [m][lane][tile][2 groups], the mixed channel tile (if any) last, same layout }.
 // ---------------------------------------------------------------------------------------------------------------------
 struct HcqPackP {
     WPtrs w[2];                  // component tensors (OA, IA, taps) of the 1 or 2 weight sets
@@ -375,26 +389,17 @@ __device__ __forceinline__ float hcq_pack_value(const HcqPackP& p, long long idx
     const int NT = p.NT1 + p.NT2;
     const int set = (int)(idx / p.set_stride);
     long long r0 = idx - (long long)set * p.set_stride;
-    const long long reg_total = (long long)p.nreg * p.ytile_stride;
-    const bool mix = r0 >= reg_total;
-    int ytile = 0;
-    long long rs[2];
-    if (mix) {
-        r0 -= reg_total;
-        rs[0] = rs[1] = (long long)p.NPAIR * 8 * 64 * 2;
-    } else {
-        ytile = (int)(r0 / p.ytile_stride);
-        r0 -= (long long)ytile * p.ytile_stride;
-        rs[0] = p.range_stride[0];
-        rs[1] = p.range_stride[1];
-    }
-    const long long chunk_stride = rs[0] + ((p.NR > 1 || mix) ? rs[1] : 0);
+    const int ytile = (int)(r0 / p.ytile_stride);
+    r0 -= (long long)ytile * p.ytile_stride;
+    const bool mix = p.has_mix && ytile == p.nreg;          // the mixed channel tile: same layout, other descriptors
+    const long long rs[2] = {p.range_stride[0], p.range_stride[1]};
+    const long long chunk_stride = rs[0] + (p.NR > 1 ? rs[1] : 0);
     const int chs = (int)(r0 / chunk_stride);            // chunk over all sources
     r0 -= (long long)chs * chunk_stride;
     const int srcsel = chs / p.nch, ch = chs - srcsel * p.nch;
     const int range = (r0 >= rs[0]) ? 1 : 0;
     if (range) r0 -= rs[0];
-    const int ntr = mix ? 1 : (range ? p.NT2 : NT);
+    const int ntr = range ? p.NT2 : NT;
     const int per_m = 64 * 2 * ntr;
     const int per_pair = 8 * per_m;
     const int j = (int)(r0 / per_pair);
@@ -408,9 +413,10 @@ __device__ __forceinline__ float hcq_pack_value(const HcqPackP& p, long long idx
     const int g = 2 * j + gg;
     if (g >= p.NG) return 0.f;
     const int kq = 4 * g + k;
-    const int ds = mix ? 2 : (range ? p.NT1 + t : t);     // descriptor slot
-    const int grp = n >> 3;
-    const int ob0 = p.tile_ob[ds][grp];
+    const int tf = range ? p.NT1 + t : t;                  // tile (accumulator slot) of the workgroup
+    const int ds = mix ? 2 : tf;                           // descriptor slot: a mixed workgroup's slot NT1 is the mixed
+    const int grp = n >> 3;                                // tile, its other slots are padding
+    const int ob0 = (mix && tf != p.NT1) ? -1 : p.tile_ob[ds][grp];
     if (ob0 < 0) return 0.f;
     const int dblk = ob0 + (mix ? 0 : ytile * p.ob_step) + (n & 7);     // destination block channel
     const int kbl = kq / p.taps;
@@ -559,8 +565,7 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
     k.range_stride[0] = (long long)NPAIR * 8 * 64 * 2 * NT;
     k.range_stride[1] = (long long)NPAIR * 8 * 64 * 2 * NT2;
     k.ytile_stride = (long long)nsrc * k.nch * (k.range_stride[0] + (NR > 1 ? k.range_stride[1] : 0));
-    const long long mix_block = mix ? (long long)nsrc * k.nch * 2 * NPAIR * 8 * 64 * 2 : 0;
-    k.set_stride = (long long)nreg * k.ytile_stride + mix_block;
+    k.set_stride = (long long)(nreg + mix) * k.ytile_stride;
     pl.pack_floats = (size_t)k.set_stride * nsets;
     HcqPackP& q = pl.pp;
     q.A = A; q.mode = mode; q.OA = d->Cout / A; q.IA = d->Cin / A; q.taps = taps;
@@ -581,7 +586,7 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
 
 // The instantiation a plan runs: staging items per thread are fixed by (taps, IBC, algebra) except for the dilated 1x3
 // layers (halo width).  Returns 0 if there is none.
-struct HcqKern { int KH, KW, IBC, NT1, NT2, NR, XI, MIX; };
+struct HcqKern { int KH, KW, IBC, NT1, NT2, NR, XI; };
 static int hcq_pick(const HcqPlan& pl, HcqKern* k) {
     int xi8 = 0, xi4 = 0;
     if (pl.KH == 1 && pl.KW == 3 && pl.IBC == 8) {
@@ -595,13 +600,13 @@ static int hcq_pick(const HcqPlan& pl, HcqKern* k) {
     else return 0;
     const int xi = pl.NR == 2 ? xi8 : xi4;
     if (pl.XI > xi) return 0;
-    *k = HcqKern{pl.KH, pl.KW, pl.IBC, pl.NT1, pl.NT2, pl.NR, xi, pl.mix};
+    *k = HcqKern{pl.KH, pl.KW, pl.IBC, pl.NT1, pl.NT2, pl.NR, xi};
     return 1;
 }
 
-template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI, bool MIX>
+template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI>
 static int hcq_launch_one(const HcqPlan& pl, hipStream_t st) {
-    auto kern = hcq_conv_kernel<KH, KW, IBC, NT1, NT2, NR, XI, MIX>;
+    auto kern = hcq_conv_kernel<KH, KW, IBC, NT1, NT2, NR, XI>;
     if (pl.smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem) != hipSuccess)
         return SELD_ELAUNCH;
@@ -613,13 +618,12 @@ template <int KH, int KW, int IBC, int XI8, int XI4>
 static int hcq_launch_cfg(const HcqPlan& pl, const HcqKern& k, hipStream_t st) {
     if (k.NR == 2) {
         if (k.XI != XI8) return SELD_EUNSUPPORTED;
-        if (k.NT2 == 2) return hcq_launch_one<KH, KW, IBC, 1, 2, 2, XI8, false>(pl, st);
-        return k.MIX ? hcq_launch_one<KH, KW, IBC, 1, 1, 2, XI8, true>(pl, st)
-                     : hcq_launch_one<KH, KW, IBC, 1, 1, 2, XI8, false>(pl, st);
+        if (k.NT2 == 2) return hcq_launch_one<KH, KW, IBC, 1, 2, 2, XI8>(pl, st);
+        return hcq_launch_one<KH, KW, IBC, 1, 1, 2, XI8>(pl, st);
     }
     if (k.XI != XI4) return SELD_EUNSUPPORTED;
-    return k.NT1 == 2 ? hcq_launch_one<KH, KW, IBC, 2, 0, 1, XI4, false>(pl, st)
-                      : hcq_launch_one<KH, KW, IBC, 1, 0, 1, XI4, false>(pl, st);
+    return k.NT1 == 2 ? hcq_launch_one<KH, KW, IBC, 2, 0, 1, XI4>(pl, st)
+                      : hcq_launch_one<KH, KW, IBC, 1, 0, 1, XI4>(pl, st);
 }
 
 static int hcq_launch(const HcqPlan& pl, hipStream_t st) {
@@ -661,8 +665,7 @@ extern "C" int seld_hcq_kernel_label(const seld_conv_desc* d, int32_t mode, int3
     const HcqPlan pl = hcq_plan(d, mode, npair);
     HcqKern k;
     if (!pl.ok || !hcq_pick(pl, &k)) return SELD_EUNSUPPORTED;
-    snprintf(buf, buflen, "hcq_conv_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", k.KH, k.KW, k.IBC, k.NT1, k.NT2, k.NR, k.XI,
-             k.MIX ? "true" : "false");
+    snprintf(buf, buflen, "hcq_conv_kernel<%d, %d, %d, %d, %d, %d, %d>", k.KH, k.KW, k.IBC, k.NT1, k.NT2, k.NR, k.XI);
     return SELD_OK;
 }
 

@@ -198,11 +198,45 @@ def conv_bwd_data(desc, dy, ws, x_shape, ahead=None):
     return dx
 
 
+def _hcq_wgrad_ok(desc, npair=1):
+    key = (bytes(desc), npair, "wgrad")
+    v = _hcq_labels.get(key)
+    if v is None:
+        v = _hcq_labels[key] = desc.algebra > 1 and bool(L.lib().seld_hcq_wgrad_supported(ctypes.byref(desc), int(npair)))
+    return v
+
+
+def _hcq_wgrad_label(desc, npair=1):
+    key = (bytes(desc), npair, "wgrad_label")
+    v = _hcq_labels.get(key)
+    if v is None:
+        buf = ctypes.create_string_buffer(96)
+        L.check(L.lib().seld_hcq_wgrad_label(ctypes.byref(desc), int(npair), buf, 96), "seld_hcq_wgrad_label")
+        v = _hcq_labels[key] = buf.value.decode()
+    return v
+
+
+def hcq_wgrad_acc(desc, x, dyA, dwA, dyB=None, dwB=None):
+    """dwA[c] += wgrad(x, dyA) [, dwB[c] += wgrad(x, dyB)] on the fast-product kernel (seld_hcq_wgrad_acc)."""
+    npair = 2 if dyB is not None else 1
+    with _Timed(desc, 2, npair, label=_hcq_wgrad_label(desc, npair) if kernel_timer.active else None):
+        L.check(L.lib().seld_hcq_wgrad_acc(ctypes.byref(desc), npair, L.ptr(x), L.ptr(dyA), L.ptr(dyB), L.ptr_array8(dwA),
+                                           L.ptr_array8(dwB) if dwB is not None else None, L.current_stream()),
+                "seld_hcq_wgrad_acc")
+
+
 def conv_bwd_weight(desc, x, dy, w_shape, want_bias, into=None, bias_into=None):
     """Component weight gradients.  `into` (list of A tensors, e.g. views of FlatAdam.flat_grad) selects the
     accumulating entry point: the kernel adds straight into them and nothing is returned for autograd."""
     x = _req(x, "x")
     dy = _req(dy, "dy")
+    if not want_bias and bias_into is None and _hcq_wgrad_ok(desc):
+        if into is not None:
+            hcq_wgrad_acc(desc, x, dy, into)
+            return None, None
+        dws = [torch.zeros(w_shape, device=x.device, dtype=torch.float32) for _ in range(desc.algebra)]
+        hcq_wgrad_acc(desc, x, dy, dws)
+        return dws, None
     if into is not None:
         with _Timed(desc, 2):
             L.check(L.lib().seld_hc_conv_bwd_weight_acc(ctypes.byref(desc), L.ptr(x), L.ptr(dy), L.ptr_array8(into),
@@ -680,7 +714,14 @@ class HyperConvPairFn(torch.autograd.Function):
         dwsA, dwsB, dbA, dbB = [None] * A, [None] * A, None, None
         if need_w:
             dirA, dirB = _direct_targets(wsA, biasA), _direct_targets(wsB, biasB)
-            if dirA is not None and dirB is not None and _pair_ok(desc, 2):
+            if dirA is not None and dirB is not None and dirA[1] is None and dirB[1] is None and _hcq_wgrad_ok(desc, 2):
+                def pair_wgrad_fast():
+                    hcq_wgrad_acc(desc, x, dyA, dirA[0], dyB, dirB[0])
+                if _side_enabled():
+                    _on_side_stream(pair_wgrad_fast, x, dyA, dyB)
+                else:
+                    pair_wgrad_fast()
+            elif dirA is not None and dirB is not None and _pair_ok(desc, 2):
                 def pair_wgrad():
                     with _Timed(desc, 2, 2):
                         L.check(lib.seld_hc_conv_pair_bwd_weight_acc(ctypes.byref(desc), L.ptr(x), L.ptr(dyA), L.ptr(dyB),

@@ -426,3 +426,38 @@ def test_hcq_pair_matches_two_single_calls(algebra, shape, cout, k, pad, dil):
             for w in wl[0] + wl[1]:
                 w.mul_(-0.5).add_(0.01)
                 w.grad = None
+
+
+@pytest.mark.parametrize("algebra,shape,cout,k,pad,dil", [HCQ_CASES[0], HCQ_CASES[2], HCQ_CASES[4], HCQ_CASES[6],
+                                                          HCQ_CASES[7], HCQ_CASES[8], HCQ_CASES[9]])
+def test_hcq_wgrad_matches_block_matrix_kernels(algebra, shape, cout, k, pad, dil, seld_env):
+    """Fast-product weight gradient (hcq_wgrad.hip: regular row tiles, the mixed 8 + 8 row tile, quaternion; single
+    and pair launches) against the 16/48-product kernels, which the oracle tests pin."""
+    import seld_amd
+    H = seld_amd.hip_ops
+    seld_env.set("SELD_HCQ_WGRAD_DQ", "1")
+    kk = (k,) if isinstance(k, int) else k
+    desc = H.make_conv_desc(tuple(shape), cout, algebra, kk, 1, pad, dil)
+    if not H._hcq_wgrad_ok(desc):
+        pytest.skip("shape not taken by the fast-product weight-gradient kernel (LDS budget)")
+    gen = torch.Generator().manual_seed(11)
+    dev = torch.device("cuda:0")
+    x = torch.randn(shape, generator=gen).to(dev)
+    wshape = (cout // algebra, shape[1] // algebra) + tuple(kk)
+    yshape = (shape[0], cout) + tuple(shape[2:])
+    dyA, dyB = torch.randn(yshape, generator=gen).to(dev), torch.randn(yshape, generator=gen).to(dev)
+    new = [[torch.zeros(wshape, device=dev) for _ in range(algebra)] for _ in range(3)]
+    H.hcq_wgrad_acc(desc, x, dyA, new[0])
+    if H._hcq_wgrad_ok(desc, 2):
+        H.hcq_wgrad_acc(desc, x, dyA, new[1], dyB, new[2])
+    seld_env.set("SELD_CONV_NO_HCQ", "1")
+    old = [[torch.zeros(wshape, device=dev) for _ in range(algebra)] for _ in range(2)]
+    H.conv_bwd_weight(desc, x, dyA, wshape, False, into=old[0])
+    H.conv_bwd_weight(desc, x, dyB, wshape, False, into=old[1])
+    for a, b in zip(new[0], old[0]):
+        _close(a, b)
+    if H._hcq_wgrad_ok(desc, 2) or True:
+        seld_env.unset("SELD_CONV_NO_HCQ")
+        if H._hcq_wgrad_ok(desc, 2):
+            for a, b in zip(new[1] + new[2], old[0] + old[1]):
+                _close(a, b)

@@ -158,7 +158,7 @@ def test_graphed_step_matches_eager_step():
     assert opt.step_count == 5
     for k in sde:
         if k.endswith("num_batches_tracked"):
-            assert int(sdg[k]) == int(sde[k]) == 5, k
+            assert int(sdg[k]) == int(sde[k]) == (0 if "batch_gate1" in k else 5), k     # batch_gate1 is never used (model.py:90)
         elif "running_" in k:
             assert torch.allclose(sdg[k], sde[k], rtol=5e-3, atol=1e-5), k
 
