@@ -67,6 +67,9 @@ struct HcqP {
 
 typedef unsigned int uintx4h __attribute__((ext_vector_type(4)));
 
+// n / d for 0 <= n < 2^20 with a precomputed 1.0f / d (exact: see hc_conv_vec.hip)
+__device__ __forceinline__ int small_div_h(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
+
 // X-form m from the 4 component values (see the header)
 __device__ __forceinline__ void xforms(const float b[4], float g[8]) {
     g[0] = b[1] + b[2];
@@ -102,54 +105,56 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     const int wext = p.wext, qw = wext >> 2;
     const int buf_floats = ROWS * wext;
 
-    // ---- tile position ------------------------------------------------------------------------------------------
-    const long long p0 = (long long)blockIdx.x * 64;  // 64 consecutive positions inside ONE row (W % 64 == 0)
-    const int rows_total = p.N * p.Himg;
-    const int row_g = (int)(p0 / p.W);                // n * Himg + h
-    const int w0 = (int)(p0 - (long long)row_g * p.W);
-    const int n_img = row_g / p.Himg;
-    const int h0 = row_g - n_img * p.Himg;
-    (void)rows_total;
+    // ---- tile position (32-bit arithmetic throughout: the host checked that both tensors are below 4 GB) ------------
+    const unsigned tiles_per_row = (unsigned)p.W >> 6;    // 64 consecutive positions inside ONE row (W % 64 == 0)
+    const unsigned row_g = blockIdx.x / tiles_per_row;    // n * Himg + h
+    const int w0 = (int)(blockIdx.x - row_g * tiles_per_row) * 64;
+    const int n_img = (int)(row_g / (unsigned)p.Himg);
+    const int h0 = (int)row_g - n_img * p.Himg;
     const int yt = blockIdx.y;                        // channel tile over all weight sets
-    const int set = yt / p.ytiles;
+    const int set = yt >= p.ytiles ? 1 : 0;           // at most two weight sets
     const int ytile = yt - set * p.ytiles;
     const bool mix_wg = ytile == p.mix_ytile;         // workgroup-uniform
 
     // ---- staging items: (row, quad) of the raw image of a chunk, everything but the chunk advance is invariant ----
-    const long long S = (long long)p.Himg * p.W;
-    const long long src_bytes = (long long)p.N * p.Csrc * S * 4;
+    const unsigned S = (unsigned)(p.Himg * p.W);
+    const unsigned src_bytes = (unsigned)p.N * (unsigned)p.Csrc * S * 4u;
     const unsigned OOB = 0xFFFFFFF0u;
-    __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, src_bytes > (long long)OOB ? OOB : (unsigned)src_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, src_bytes, 0x00020000);
     unsigned xoff[XI];
     int xlds[XI];
-    const unsigned xadv = (unsigned)((long long)IBC * S * 4);
+    const unsigned xadv = (unsigned)IBC * S * 4u;
     const int total_items = ROWS * qw;
+    {
+        // item f = tid + 256 i  ->  (row, quad) = (f / qw, f % qw): one division, then increments
+        int row = small_div_h(tid, 1.0f / (float)qw);
+        int quad = tid - row * qw;
+        const int drow = 256 / qw, dquad = 256 - drow * qw;       // wave-uniform
+        const unsigned img_base = (unsigned)n_img * (unsigned)p.Csrc * S;
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int f = tid + 256 * i;
-        const bool in = f < total_items;
-        const int ff = in ? f : 0;
-        const int row = ff / qw;
-        const int quad = ff - row * qw;
-        // row = (comp * IBC + ibl) * KH + kh
-        const int kh = row % KH;
-        const int ci = row / KH;
-        const int comp = ci / IBC;
-        const int ibl = ci - comp * IBC;
-        const int hh = h0 + (kh - (KH - 1) / 2);
-        const int ww = w0 - p.dpad + 4 * quad;
-        const bool ok = in && (unsigned)hh < (unsigned)p.Himg && (unsigned)ww < (unsigned)p.W;
-        const long long e = (((long long)n_img * p.Csrc + comp * p.IB + ibl) * p.Himg + hh) * p.W + ww;
-        xoff[i] = ok ? (unsigned)(e * 4) : OOB;
-        xlds[i] = in ? ff * 4 : -1;                    // float index of the quad in the LDS image; -1: no store
+        for (int i = 0; i < XI; ++i) {
+            const bool in = tid + 256 * i < total_items;
+            // row = (comp * IBC + ibl) * KH + kh, all divisors compile-time
+            const int kh = row % KH;
+            const int ci = row / KH;
+            const int comp = ci / IBC;
+            const int ibl = ci - comp * IBC;
+            const int hh = h0 + (kh - (KH - 1) / 2);
+            const int ww = w0 - p.dpad + 4 * quad;
+            const bool ok = in && (unsigned)hh < (unsigned)p.Himg && (unsigned)ww < (unsigned)p.W;
+            const unsigned e = img_base + ((unsigned)(comp * p.IB + ibl) * (unsigned)p.Himg + (unsigned)hh) * (unsigned)p.W + (unsigned)ww;
+            xoff[i] = ok ? e * 4u : OOB;
+            xlds[i] = in ? (row * qw + quad) * 4 : -1;     // float index of the quad in the LDS image; -1: no store
+            row += drow;
+            quad += dquad;
+            if (quad >= qw) { quad -= qw; ++row; }
+        }
     }
     floatx4 xr[XI];
     int xchunk = 0;                                    // chunks requested so far
     auto load_x = [&]() __attribute__((always_inline)) {
         if (xchunk == p.nch) {                         // second source of a pair: same offsets, other tensor
-            rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src2, 0, src_bytes > (long long)OOB ? OOB : (unsigned)src_bytes,
-                                                     0x00020000);
+            rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src2, 0, src_bytes, 0x00020000);
 #pragma unroll
             for (int i = 0; i < XI; ++i) xoff[i] = xoff[i] == OOB ? OOB : xoff[i] - (unsigned)p.nch * xadv;
         }
@@ -194,37 +199,26 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
 
     // ---- one K chunk = range 0's NG k-groups, then range 1's.  Software pipeline, forced with scheduling barriers
     // (left alone, the compiler sinks every fragment load to just before its MFMA and waits for it there: 43 % MFMA busy):
-    //   * weight fragments come in pairs of k-groups; the pair after the current one (or the next chunk's first pair)
-    //     is requested when the current pair starts, into the other half of a two-stage register buffer;
+    //   * weight fragments come in pairs of k-groups, one register pair per form; a form's registers are re-requested
+    //     for the next pair (or the next chunk's first pair) right after their last MFMA, so every request has the other
+    //     seven forms' MFMAs and the next group's first ones in front of its use -- one stage instead of two keeps the
+    //     kernel at 3 waves per SIMD;
     //   * the raw component values of k-group g+1 are read from LDS at the start of group g and turned into the 8 sums
     //     under the MFMAs of group g, so no VALU result feeds the very next MFMA.
-    float2 bfr[2][8][NT];
+    float2 bfr[8][NT];                                       // ONE stage: form m's pair is re-requested right after its last use
     float gm[2][8];
     float raw[4];
     constexpr int NPC = NR * NPAIR;                          // fragment pairs per chunk
-    constexpr bool CARRY = (NPC % 2) == 0;                   // stage parity survives a chunk: prefetch across chunks
 
-    auto load_b = [&](const float* blk, int j, int stage, auto ntrc) __attribute__((always_inline)) {
+    auto load_b1 = [&](const float* blk, int j, int m, auto ntrc) __attribute__((always_inline)) {
         constexpr int NTR = decltype(ntrc)::value;
-        const float* q = blk + ((long long)j * 8 * 64 + lane) * (2 * NTR);
+        const float* q = blk + ((long long)(j * 8 + m) * 64 + lane) * (2 * NTR);
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-            for (int t = 0; t < NTR; ++t)
-                bfr[stage][m][t] = *reinterpret_cast<const float2*>(q + (long long)m * 64 * 2 * NTR + 2 * t);
+        for (int t = 0; t < NTR; ++t) bfr[m][t] = *reinterpret_cast<const float2*>(q + 2 * t);
     };
     auto read_raw = [&](const float* xs, int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) raw[q] = xs[aoff[g] + q * comp_stride];
-    };
-    auto mfma_group = [&](int bstage, int gg, int gstage, auto t0c, auto ntrc) __attribute__((always_inline)) {
-        constexpr int T0 = decltype(t0c)::value, NTR = decltype(ntrc)::value;
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-            for (int t = 0; t < NTR; ++t)
-                acc[T0 + t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                    gm[gstage][m], gg ? bfr[bstage][m][t].y : bfr[bstage][m][t].x, acc[T0 + t][m], 0, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>;
     using INT = std::integral_constant<int, NT>;
@@ -235,42 +229,56 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     const int nchunks = p.nch * p.nsrc;
     load_x();
     store_x(0);
-    load_b(wbase, 0, 0, INT{});
+#pragma unroll
+    for (int m = 0; m < 8; ++m) load_b1(wbase, 0, m, INT{});
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < nchunks) load_x();
         const float* xb = lds + buf * buf_floats;
         const float* wc = wbase + (long long)ch * chunk_stride;
-        const float* wn = ch + 1 < nchunks ? wc + chunk_stride : nullptr;
+        const bool more = ch + 1 < nchunks;
+        const float* wn = wc + chunk_stride;
         const float* xs0 = xb + p.half_src[0] * 4 * comp_stride;
         const float* xs1 = xb + p.half_src[1] * 4 * comp_stride;
-        if (!CARRY && ch > 0) load_b(wc, 0, 0, INT{});
         read_raw(xs0, 0);
         xforms(raw, gm[0]);
 #pragma unroll
         for (int s = 0; s < NR * NG; ++s) {                   // k-groups of the chunk, both ranges
             const int r = s / NG, g = s - r * NG;
             const int pc = r * NPAIR + g / 2;                // fragment pair of this group within the chunk
-            const int bst = pc & 1, gst = s & 1;
+            const int gst = s & 1;
             const bool last = s + 1 == NR * NG;
-            if ((g & 1) == 0) {                               // a new pair starts: request the one after it
-                const int pn = pc + 1;
-                if (pn < NPC) {
-                    const int rn = pn / NPAIR, jn = pn - rn * NPAIR;
-                    if (rn == 0) load_b(wc, jn, bst ^ 1, INT{});
-                    else load_b(wc + p.range_stride[0], jn, bst ^ 1, INT2{});
-                } else if (CARRY && wn) {
-                    load_b(wn, 0, bst ^ 1, INT{});
-                }
-            }
+            const bool pair_ends = (g & 1) == 1 || g + 1 == NG;   // last k-group that uses the current fragments
             if (!last) {
                 const int rn = (s + 1) / NG, gn = (s + 1) - rn * NG;
                 read_raw(rn == 0 ? xs0 : xs1, gn);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (r == 0) mfma_group(bst, g & 1, gst, I0{}, INT{});
-            else mfma_group(bst, g & 1, gst, INT1{}, INT2{});
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (r == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gm[gst][m], (g & 1) ? bfr[m][t].y : bfr[m][t].x,
+                                                                          acc[t][m], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT2; ++t)
+                        acc[NT1 + t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gm[gst][m], (g & 1) ? bfr[m][t].y : bfr[m][t].x,
+                                                                                acc[NT1 + t][m], 0, 0, 0);
+                }
+                if (pair_ends) {                              // form m's fragments are free: request the next pair's
+                    const int pn = pc + 1;
+                    if (pn < NPC) {
+                        const int rn = pn / NPAIR, jn = pn - rn * NPAIR;
+                        if (rn == 0) load_b1(wc, jn, m, INT{});
+                        else load_b1(wc + p.range_stride[0], jn, m, INT2{});
+                    } else if (more) {
+                        load_b1(wn, 0, m, INT{});
+                    }
+                }
+            }
             if (!last) xforms(raw, gm[gst ^ 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -285,60 +293,69 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     float* const stats = p.stats[set];
     const int epi = p.epilogue[set];
     const int grp = fr >> 3;
-    const long long pos_off = (long long)h0 * p.W + w0 + wave * 16 + fk * 4;
+    const unsigned pos_off = (unsigned)h0 * (unsigned)p.W + (unsigned)(w0 + wave * 16 + fk * 4);
+    const unsigned img_off = (unsigned)n_img * (unsigned)p.Cdst * S;
     float* redbuf = lds;                       // the K loop is over (last barrier passed): staging buffers are free
+    // PLAIN: no bias / addend / accumulate / statistics (every data gradient, the plain forward): stores only
+    auto epilogue = [&](auto plainc) __attribute__((always_inline)) {
+        constexpr bool PLAIN = decltype(plainc)::value;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        // a mixed-tile workgroup: accumulator slot NT1 is descriptor slot 2, the other slots are padding
-        const int ds = mix_wg ? 2 : t;
-        const int ob0 = (mix_wg && t != NT1) ? -1 : p.tile_ob[ds][grp];
-        const int half = p.tile_half[ds][grp];
-        const bool chok = ob0 >= 0;
-        const int ob = (chok ? ob0 : 0) + (mix_wg ? 0 : ytile * p.ob_step) + (fr & 7);
-        floatx4 hsum, c[4];
+        for (int t = 0; t < NT; ++t) {
+            // a mixed-tile workgroup: accumulator slot NT1 is descriptor slot 2, the other slots are padding
+            const int ds = mix_wg ? 2 : t;
+            const int ob0 = (mix_wg && t != NT1) ? -1 : p.tile_ob[ds][grp];
+            const int half = p.tile_half[ds][grp];
+            const bool chok = ob0 >= 0;
+            const int ob = (chok ? ob0 : 0) + (mix_wg ? 0 : ytile * p.ob_step) + (fr & 7);
+            floatx4 c[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hsum[r] = 0.5f * acc[t][3][r];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float h0_ = 0.5f * acc[t][0][r], h1 = 0.5f * acc[t][1][r], h2 = 0.5f * acc[t][2][r];
-            c[0][r] = (hsum[r] - h0_) + (h1 + h2) + acc[t][4][r];
-            c[1][r] = (hsum[r] - h0_) - (h1 + h2) + acc[t][5][r];
-            c[2][r] = (hsum[r] + h0_) + (h2 - h1) + acc[t][6][r];
-            c[3][r] = (hsum[r] + h0_) + (h1 - h2) - acc[t][7][r];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int chn = (half * 4 + q) * p.OB + ob;           // component-major channel index
-            float s1 = 0.f, s2 = 0.f;
-            if (chok) {
-                const float bv = bias ? bias[chn] : 0.f;
-                const long long off = ((long long)n_img * p.Cdst + chn) * S + pos_off;
-                float4 o = make_float4(c[q][0] + bv, c[q][1] + bv, c[q][2] + bv, c[q][3] + bv);
-                if (epi & SELD_EPI_ADD) {
-                    const float4 ad = *reinterpret_cast<const float4*>(addend + off);
-                    o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
-                }
-                if (epi & SELD_EPI_ACCUMULATE) {
-                    const float4 old = *reinterpret_cast<const float4*>(dst + off);
-                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-                }
-                *reinterpret_cast<float4*>(dst + off) = o;
-                s1 = o.x + o.y + o.z + o.w;
-                s2 = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+            for (int r = 0; r < 4; ++r) {
+                const float h0_ = 0.5f * acc[t][0][r], h1 = 0.5f * acc[t][1][r], h2 = 0.5f * acc[t][2][r], h3 = 0.5f * acc[t][3][r];
+                c[0][r] = (h3 - h0_) + (h1 + h2) + acc[t][4][r];
+                c[1][r] = (h3 - h0_) - (h1 + h2) + acc[t][5][r];
+                c[2][r] = (h3 + h0_) + (h2 - h1) + acc[t][6][r];
+                c[3][r] = (h3 + h0_) + (h1 - h2) - acc[t][7][r];
             }
-            if (epi & SELD_EPI_STATS) {
-                s1 += __shfl_xor(s1, 16, 64);
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 16, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (fk == 0) {
-                    const int slot = ((wave * NT + t) * 4 + q) * 16 + fr;
-                    redbuf[slot * 2 + 0] = s1;
-                    redbuf[slot * 2 + 1] = s2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int chn = (half * 4 + q) * p.OB + ob;           // component-major channel index
+                const unsigned off = img_off + (unsigned)chn * S + pos_off;
+                if (PLAIN) {
+                    if (chok) *reinterpret_cast<float4*>(dst + off) = make_float4(c[q][0], c[q][1], c[q][2], c[q][3]);
+                    continue;
+                }
+                float s1 = 0.f, s2 = 0.f;
+                if (chok) {
+                    const float bv = bias ? bias[chn] : 0.f;
+                    float4 o = make_float4(c[q][0] + bv, c[q][1] + bv, c[q][2] + bv, c[q][3] + bv);
+                    if (epi & SELD_EPI_ADD) {
+                        const float4 ad = *reinterpret_cast<const float4*>(addend + off);
+                        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                    }
+                    if (epi & SELD_EPI_ACCUMULATE) {
+                        const float4 old = *reinterpret_cast<const float4*>(dst + off);
+                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                    }
+                    *reinterpret_cast<float4*>(dst + off) = o;
+                    s1 = o.x + o.y + o.z + o.w;
+                    s2 = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+                }
+                if (epi & SELD_EPI_STATS) {
+                    s1 += __shfl_xor(s1, 16, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 16, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (fk == 0) {
+                        const int slot = ((wave * NT + t) * 4 + q) * 16 + fr;
+                        redbuf[slot * 2 + 0] = s1;
+                        redbuf[slot * 2 + 1] = s2;
+                    }
                 }
             }
         }
-    }
+    };
+    if (epi == 0 && !bias) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if (epi & SELD_EPI_STATS) {
         __syncthreads();
         float* rep = stats + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
@@ -498,7 +515,7 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
     if (W % 64) return pl;
     const int Csrc = mode == 0 ? d->Cin : d->Cout, Cdst = mode == 0 ? d->Cout : d->Cin;
     const int IB = Csrc / A, OB = Cdst / A;
-    if ((long long)d->N * Csrc * Himg * W * 4 >= 0xFFFFFFF0ll) return pl;
+    if ((long long)d->N * Csrc * Himg * W * 4 >= 0xFFFFFFF0ll || (long long)d->N * Cdst * Himg * W * 4 >= 0xFFFFFFF0ll) return pl;
     const int taps = KH * KW;
     const int nsets = mode == 0 ? npair : 1, nsrc = mode == 1 ? npair : 1;
     const int dil = KW == 3 ? d->dil[1] : 0;

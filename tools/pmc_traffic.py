@@ -44,7 +44,7 @@ def main():
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         res[label(k)] = dict(fetch_bytes=2.0 * f * 1024.0, write_bytes=w * 1024.0,
                              traffic_bytes=2.0 * f * 1024.0 + w * 1024.0, launches_sampled=nf.get(k, 0))
-    json.dump(dict(note="per launch; FETCH_SIZE x2 (gfx950 correction), units KiB", kernels=res), open(out, "w"), indent=1)
+    json.dump(dict(note="bytes per launch (mean over the sampled launches); the counters print KiB, FETCH_SIZE is doubled (gfx950 correction)", kernels=res), open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes"])[:12]:
         print(f"{v['traffic_bytes'] / 1e6:10.1f} MB  {k}")
 
