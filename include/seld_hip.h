@@ -240,6 +240,14 @@ int seld_bn_act_bwd_apply(const float* dy, const float* x, const float* y, int32
                           const float* mean, const float* invstd, const float* gamma, const float* beta,
                           int32_t act, const float* dgamma_dbeta, int32_t train, float* dx, void* stream);
 
+/* One-pass training-mode backward of the same op: dgamma / dbeta are ADDED to dgamma_dbeta (it need not be zero),
+ * dx = BatchNorm-backward((dy [+ dy2]) * act'(y))  (dx nullable: parameter gradients only; dy2 nullable: the gradient
+ * from y's second consumer -- the residual sum x_hat + conv2_residual(..) of model.py:132 -- added on load instead of
+ * by a separate kernel).  SELD_EUNSUPPORTED when S % 4 != 0 or N*S > 32768: use the reduce + apply pair. */
+int seld_bn_act_bwd_fused(const float* dy, const float* x, const float* y, int32_t N, int32_t C, int32_t S,
+                          const float* mean, const float* invstd, const float* gamma, int32_t act,
+                          float* dgamma_dbeta, const float* dy2, float* dx, void* stream);
+
 /* gated activation of the residual block (model.py:121-128):
  *   y = tanh(bn_f(yf)) * sigmoid(bn_g(yg)) * mask[n, c]      (mask nullable = Dropout1d channel mask,
  *                                                            already scaled by 1/(1-p))            */
@@ -257,6 +265,12 @@ int seld_gate_bwd_apply(const float* dy, const float* yf, const float* yg, int32
                         const float* mean_f, const float* invstd_f, const float* gamma_f, const float* beta_f,
                         const float* mean_g, const float* invstd_g, const float* gamma_g, const float* beta_g,
                         const float* mask, const float* red, int32_t train, float* dyf, float* dyg, void* stream);
+
+/* One-pass training-mode backward of the gate (adds into red[4C]; SELD_EUNSUPPORTED when S % 4 != 0 or N*S > 16384). */
+int seld_gate_bwd_fused(const float* dy, const float* yf, const float* yg, int32_t N, int32_t C, int32_t S,
+                        const float* mean_f, const float* invstd_f, const float* gamma_f, const float* beta_f,
+                        const float* mean_g, const float* invstd_g, const float* gamma_g, const float* beta_g,
+                        const float* mask, float* red, float* dyf, float* dyg, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Quaternion / dual-quaternion convolution by the 8-multiplication Hamilton product (csrc/hcq_conv.hip).

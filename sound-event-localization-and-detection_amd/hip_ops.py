@@ -860,11 +860,16 @@ def _claim_grad_slots(params, adjacent=True):
     return ts[0].grad, clean
 
 
+def _one_pass_ok(N, S, limit):
+    """The one-workgroup-per-channel backward kernels (csrc/nn_ops.hip) hold a channel's N*S values in registers."""
+    return S % 4 == 0 and N * S <= limit and not os.environ.get("SELD_BN_TWO_PASS")
+
+
 class BnActFn(torch.autograd.Function):
     """y = act(BatchNorm(x)); torch.nn.BatchNorm1d/2d + ReLU/Tanh of model.py:114-116, 279-280."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, stats, nbt):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, stats, nbt, twin):
         x = _req(x, "x")
         N, C, S = _ncs(x)
         mean, invstd = bn_prepare(x, running_mean, running_var, training, momentum, eps, stats, nbt)
@@ -874,18 +879,42 @@ class BnActFn(torch.autograd.Function):
         ctx.training, ctx.act = training, act
         ctx.bn_params = (gamma, beta)
         ctx.save_for_backward(x, y, mean, invstd)
+        ctx.twin = twin
+        if twin:
+            # the same values twice: each consumer's gradient then arrives separately and backward adds them while
+            # it loads them (the autograd engine would launch an add kernel for a tensor used twice)
+            ctx.set_materialize_grads(False)
+            return y, y.view_as(y)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         x, y, mean, invstd = ctx.saved_tensors
         gamma, beta = ctx.bn_params
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            return (None,) * 12
         dy = _req(dy, "dy")
+        dy2 = _req(dy2, "dy2") if dy2 is not None else None
+        none = (None,) * 9
         N, C, S = _ncs(x)
         slot, clean = _claim_grad_slots((gamma, beta))
+        st = L.current_stream()
+        if ctx.training and _one_pass_ok(N, S, 32768):
+            # one workgroup per channel: reads every operand once and ADDS [dgamma | dbeta] to `red`
+            red = slot if slot is not None else torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+            dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            L.check(L.lib().seld_bn_act_bwd_fused(L.ptr(dy), L.ptr(x), L.ptr(y), N, C, S, L.ptr(mean), L.ptr(invstd),
+                                                  L.ptr(gamma), ctx.act, L.ptr(red), L.ptr(dy2), L.ptr(dx), st),
+                    "seld_bn_act_bwd_fused")
+            if slot is not None:
+                return (dx, None, None) + none
+            return (dx, red[:C], red[C:]) + none
+        if dy2 is not None:
+            dy = dy + dy2
         # [dgamma | dbeta]: reduced straight into the (still zero) flat-gradient slots when possible
         red = slot if clean else torch.zeros(2 * C, device=x.device, dtype=torch.float32)
-        st = L.current_stream()
         L.check(L.lib().seld_bn_act_bwd_reduce(L.ptr(dy), L.ptr(x), L.ptr(y), N, C, S, L.ptr(mean), L.ptr(invstd),
                                                L.ptr(gamma), L.ptr(beta), ctx.act, L.ptr(red), st),
                 "seld_bn_act_bwd_reduce")
@@ -898,14 +927,15 @@ class BnActFn(torch.autograd.Function):
         if slot is not None:
             if not clean:
                 axpy_(slot, red, 2 * C)
-            return dx, None, None, None, None, None, None, None, None, None, None
-        return dx, red[:C], red[C:], None, None, None, None, None, None, None, None
+            return (dx, None, None) + none
+        return (dx, red[:C], red[C:]) + none
 
 
-def bn_act(x, bn, act, stats=None):
-    """`bn` is a torch.nn.BatchNorm*-shaped module (weight, bias, running_mean, running_var, ...)."""
+def bn_act(x, bn, act, stats=None, twin=False):
+    """`bn` is a torch.nn.BatchNorm*-shaped module (weight, bias, running_mean, running_var, ...).  twin=True returns
+    the result twice (two tensors, one storage) for a result with two consumers: see BnActFn.forward."""
     return BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
-                         bn.momentum if bn.momentum is not None else 0.1, bn.eps, act, stats, _nbt(bn))
+                         bn.momentum if bn.momentum is not None else 0.1, bn.eps, act, stats, _nbt(bn), twin)
 
 
 class GateFn(torch.autograd.Function):
@@ -936,9 +966,20 @@ class GateFn(torch.autograd.Function):
         dy = _req(dy, "dy")
         N, C, S = _ncs(yf)
         slot, clean = _claim_grad_slots((gf, bf, gg, bg))
+        st = L.current_stream()
+        if ctx.training and _one_pass_ok(N, S, 16384):
+            red = slot if slot is not None else torch.zeros(4 * C, device=yf.device, dtype=torch.float32)
+            dyf, dyg = torch.empty_like(yf), torch.empty_like(yg)
+            L.check(L.lib().seld_gate_bwd_fused(L.ptr(dy), L.ptr(yf), L.ptr(yg), N, C, S, L.ptr(mf), L.ptr(isf),
+                                                L.ptr(gf), L.ptr(bf), L.ptr(mg), L.ptr(isg), L.ptr(gg), L.ptr(bg),
+                                                L.ptr(mask), L.ptr(red), L.ptr(dyf), L.ptr(dyg), st),
+                    "seld_gate_bwd_fused")
+            if slot is not None:
+                return (dyf, dyg) + (None,) * 16
+            return (dyf, dyg, red[:C], red[C:2 * C], None, None, red[2 * C:3 * C], red[3 * C:], None, None,
+                    None, None, None, None, None, None, None, None)
         # [dgamma_f | dbeta_f | dgamma_g | dbeta_g]
         red = slot if clean else torch.zeros(4 * C, device=yf.device, dtype=torch.float32)
-        st = L.current_stream()
         args = (L.ptr(dy), L.ptr(yf), L.ptr(yg), N, C, S, L.ptr(mf), L.ptr(isf), L.ptr(gf), L.ptr(bf),
                 L.ptr(mg), L.ptr(isg), L.ptr(gg), L.ptr(bg), L.ptr(mask))
         L.check(L.lib().seld_gate_bwd_reduce(*args, L.ptr(red), st), "seld_gate_bwd_reduce")

@@ -142,8 +142,11 @@ class ResBlock(nn.Module):
         x_stats are those of this block's input (from the previous block), the returned ones go to the next block."""
         bn = self.batch_norm in _TCN_BN
         train_stats = bn and self.training
+        x_res = x
         if bn:
-            x = H.bn_act(x, self.batch_filter1, L.SELD_ACT_TANH, x_stats if self.batch_filter1.training else None)
+            # x_hat feeds the dilated convolutions AND the residual sum: two handles on one tensor (hip_ops.BnActFn)
+            x, x_res = H.bn_act(x, self.batch_filter1, L.SELD_ACT_TANH,
+                                x_stats if self.batch_filter1.training else None, twin=True)
         st_f = H.new_stats(self.batch_filter2.num_features, x.device) if train_stats else None
         st_g = H.new_stats(self.batch_gate2.num_features, x.device) if train_stats else None
         yf, yg = self._conv_pair(self.conv1_filter, self.conv1_gate, x, None, None, st_f, st_g)
@@ -158,7 +161,7 @@ class ResBlock(nn.Module):
         if need_residual:
             if want_res_stats and train_stats:
                 res_stats = H.new_stats(self.batch_filter1.num_features, x.device)
-            skip, res = self._conv_pair(self.conv2_skip, self.conv2_residual, y, skip_sum, x, None, res_stats)
+            skip, res = self._conv_pair(self.conv2_skip, self.conv2_residual, y, skip_sum, x_res, None, res_stats)
         else:
             skip, res = self._conv(self.conv2_skip, y, skip_sum), None
         return res, skip, res_stats

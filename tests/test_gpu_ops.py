@@ -63,9 +63,14 @@ def test_real_linear_large():
     _close(lin.bias.grad, b64.grad)
 
 
-@pytest.mark.parametrize("shape,act", [((4, 24, 100), 2), ((2, 16, 12, 64), 1), ((3, 8, 77), 0), ((2, 8, 5, 9), 3)])
-@pytest.mark.parametrize("training", [True, False])
-def test_bn_act(shape, act, training):
+@pytest.mark.parametrize("shape,act", [((4, 24, 100), 2), ((2, 16, 12, 64), 1), ((3, 8, 77), 0), ((2, 8, 5, 9), 3),
+                                       ((32, 12, 512), 2), ((48, 8, 512), 1), ((24, 8, 2048), 2)])
+@pytest.mark.parametrize("training,two_pass", [(True, False), (True, True), (False, False)])
+def test_bn_act(shape, act, training, two_pass, monkeypatch):
+    """Training mode runs the one-workgroup-per-channel backward where a channel fits (N*S <= 32768, S % 4 == 0:
+    1, 2, 4 and 8 register groups per thread are all here) and the reduce + apply pair otherwise / when forced."""
+    if two_pass:
+        monkeypatch.setenv("SELD_BN_TWO_PASS", "1")
     H, hnn = pkg().hip_ops, pkg().hip_nn
     torch.manual_seed(1)
     C = shape[1]
@@ -97,11 +102,43 @@ def test_bn_act(shape, act, training):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
-@pytest.mark.parametrize("training", [True, False])
-def test_gate(training):
+@pytest.mark.parametrize("shape,two_pass", [((6, 8, 96), False), ((6, 8, 96), True), ((5, 8, 33), False)])
+def test_bn_act_twin_outputs_sum_their_gradients(shape, two_pass, monkeypatch):
+    """ResBlock's x_hat has two consumers (model.py:116-132): bn_act(twin=True) hands out two handles and adds the two
+    incoming gradients inside its backward kernel.  Also with one handle unused."""
     H, hnn = pkg().hip_ops, pkg().hip_nn
+    if two_pass:
+        monkeypatch.setenv("SELD_BN_TWO_PASS", "1")
+    torch.manual_seed(5)
+    C = shape[1]
+    bn = hnn.BatchNorm1d(C).to(DEV).train()
+    ref = torch.nn.BatchNorm1d(C).double().train()
+    x = torch.randn(shape) * 0.7 + 0.2
+    c1, c2 = torch.randn(shape), torch.randn(shape)
+    for use_second in (True, False):
+        bn.zero_grad(); ref.zero_grad()
+        xd = x.to(DEV).requires_grad_(True)
+        a, b = H.bn_act(xd, bn, 2, twin=True)
+        assert a.data_ptr() == b.data_ptr()
+        loss = (a * c1.to(DEV)).sum() + ((b * c2.to(DEV)).sum() if use_second else 0.0)
+        loss.backward()
+        x64 = x.double().requires_grad_(True)
+        yr = torch.tanh(ref(x64))
+        ((yr * c1.double()).sum() + ((yr * c2.double()).sum() if use_second else 0.0)).backward()
+        _close(xd.grad, x64.grad, rel=2e-4, what="dx")
+        _close(bn.weight.grad, ref.weight.grad, rel=2e-4, what="dgamma")
+        _close(bn.bias.grad, ref.bias.grad, rel=2e-4, what="dbeta")
+
+
+@pytest.mark.parametrize("training,two_pass,nct", [(True, False, (3, 16, 52)), (True, True, (3, 16, 52)),
+                                                   (False, False, (3, 16, 52)), (True, False, (32, 8, 512)),
+                                                   (True, False, (12, 8, 512)), (True, False, (40, 8, 512))])
+def test_gate(training, two_pass, nct, monkeypatch):
+    H, hnn = pkg().hip_ops, pkg().hip_nn
+    if two_pass:
+        monkeypatch.setenv("SELD_BN_TWO_PASS", "1")
     torch.manual_seed(2)
-    N, C, T = 3, 16, 52
+    N, C, T = nct
     bf, bg = hnn.BatchNorm1d(C).to(DEV), hnn.BatchNorm1d(C).to(DEV)
     for b in (bf, bg):
         with torch.no_grad():
