@@ -233,7 +233,8 @@ def dp_train_step(model, optimizer, sync, x, target, n_sed, loss_fn, sed_weight=
         cut.reset()
     sed, doa = model(x)
     loss = loss_fn(sed, doa, target, n_sed, sed_weight, doa_weight)
-    loss.backward()
+    from .hip_ops import backward_from_loss
+    backward_from_loss(loss)
     if x.is_cuda:
         _join_side_stream()
     if isinstance(sync, BucketedGradSync):

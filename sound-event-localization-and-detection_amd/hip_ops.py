@@ -1319,7 +1319,27 @@ class SeldLossFn(torch.autograd.Function):
     def backward(ctx, g):
         dsed, ddoa = ctx.saved_tensors
         s1, s2 = ctx.shapes
+        if g.data_ptr() == unit_gradient(g.device).data_ptr():       # backward_from_loss(): d loss / d loss = 1
+            return dsed.reshape(s1), ddoa.reshape(s2), None, None, None
         return (dsed * g).reshape(s1), (ddoa * g).reshape(s2), None, None, None
+
+
+_unit_gradients = {}
+
+
+def unit_gradient(device):
+    """The constant 1.0 the training step seeds the backward pass with: one cached tensor per device, so neither the
+    autograd engine (ones_like -> fill) nor SeldLossFn.backward (gradient * 1.0) launches a kernel for it."""
+    device = torch.device(device)
+    t = _unit_gradients.get(device)
+    if t is None:
+        t = _unit_gradients[device] = torch.ones((), device=device, dtype=torch.float32)
+    return t
+
+
+def backward_from_loss(loss):
+    """loss.backward() seeded with the cached unit gradient."""
+    loss.backward(unit_gradient(loss.device))
 
 
 def seld_loss(sed, doa, target, w_sed=1.0, w_doa=5.0):

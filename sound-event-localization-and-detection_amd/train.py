@@ -248,7 +248,7 @@ class GraphedTrainStep:
             self.cut.reset()
         sed, doa = self.model(self.x)
         loss = seld_loss_fn(sed, doa, self.target, self.n_sed, *self.w)
-        loss.backward()
+        H.backward_from_loss(loss)
         if self.cut is not None:
             self.cut.finish()
         H.join_side_stream()
@@ -265,7 +265,7 @@ class GraphedTrainStep:
             self.cut.reset()
         sed, doa = self.model(self.x)
         loss = seld_loss_fn(sed, doa, self.target, self.n_sed, *self.w)
-        loss.backward()
+        H.backward_from_loss(loss)
         H.join_side_stream()
         return loss.detach()
 

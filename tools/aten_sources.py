@@ -19,7 +19,7 @@ step = lambda: DP.dp_train_step(model, opt, sync, x, target, 42, T.seld_loss_fn)
 for _ in range(3): step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
 import collections
 agg = collections.Counter()
@@ -27,7 +27,7 @@ for ev in prof.events():
     n = ev.name
     if n.startswith("aten::") and any(k in n for k in ("add", "copy_", "fill_", "zero_", "clone", "contiguous", "mul", "cat", "zeros")):
         st = [f for f in (ev.stack or []) if "sound-event" in f or "bench" in f or "train.py" in f]
-        agg[(n, st[0] if st else "<autograd engine / no python frame>")] += 1
+        agg[(n, (st[0] if st else "<autograd engine / no python frame>") + "  " + str(ev.input_shapes)[:90])] += 1
 for (n, where), c in sorted(agg.items(), key=lambda kv: -kv[1])[:40]:
     print(f"{c:4d}  {n:22s} {where}")
 
