@@ -53,6 +53,9 @@ FIRST_LAYER_KERNEL = "hc_conv_smallk_kernel"     # cnn.0 forward: the one HBM-bo
 
 
 def model_kwargs(w, freq=128, time_dim=512):
+    """freq = 128 is the shape BASELINE.json's metric is quoted on (U = L); freq = 256 is the config-exact
+    input (App. C G3), where the TCN is twice as wide (L = 2 x filters), so U doubles with it."""
+    w = dict(w, U=w["U"] * (freq // 128))
     return dict(time_dim=time_dim, freq_dim=freq, input_channels=w["input_channels"], output_classes=14,
                 domain=w["domain"], domain_classifier=w["domain_classifier"], cnn_filters=w["cnn_filters"],
                 kernel_size_cnn_blocks=3, pool_size=[[8, 2], [8, 2], [2, 2]], pool_time="TCN", D=[10],
@@ -90,7 +93,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(w, seconds_budget=14.0):
+def cpu_baseline(w, freq=128, seconds_budget=14.0):
     """The oracle (CPU restatement of the reference's algorithm, `assembled` = one real conv per layer exactly as
     quaternion_ops.py:125-147 does) timed on this host: same step definition, dropout on, B = min(B, 8), at all host
     threads and at 8; a bounded sample: one warm-up step, then the median of up to 5 steps within
@@ -99,7 +102,7 @@ def cpu_baseline(w, seconds_budget=14.0):
     import numpy as np
     pkg = importlib.import_module(PKG)
     batch = min(w["batch"], 8)
-    kw = model_kwargs(w)
+    kw = model_kwargs(w, freq)
     np.random.seed(1)
     torch.manual_seed(1)
     m = pkg.model.SELD_Model(**kw)           # host-side construction only (weights); never run on the CPU
@@ -108,7 +111,7 @@ def cpu_baseline(w, seconds_budget=14.0):
     cfg = O.SeldConfig(**kw)
     opt = torch.optim.Adam(leaves, lr=1e-4)
     g = torch.Generator().manual_seed(1234)
-    x = torch.randn(batch, w["input_channels"], 128, 512, generator=g)
+    x = torch.randn(batch, w["input_channels"], freq, 512, generator=g)
     target = torch.cat(((torch.rand(batch, 64, 42, generator=g) < 0.1).float(),
                         torch.rand(batch, 64, 126, generator=g) * 2 - 1), 2)
 
@@ -145,6 +148,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--freq", type=int, default=128, choices=[128, 256],
+                    help="frequency bins of the input: 128 = the shape the metric is quoted on, 256 = config-exact")
     ap.add_argument("--mode", default=os.environ.get("SELD_BENCH_MODE", "graph"), choices=["graph", "eager"])
     ap.add_argument("--roofline-steps", type=int, default=5, help="instrumented eager steps after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,11 +176,11 @@ def main():
     np.random.seed(1)
     torch.manual_seed(1)
     DP.seed_rank_streams(rank)
-    model = pkg.model.SELD_Model(**model_kwargs(w)).to(dev).train()
+    model = pkg.model.SELD_Model(**model_kwargs(w, args.freq)).to(dev).train()
     opt = T.FlatAdam(model.parameters(), lr=1e-4, late=DP.late_parameters(model) if world > 1 else None)
     DP.broadcast_parameters(opt.flat_param)
     sync = DP.BucketedGradSync(opt, model)
-    x, target = T.synthetic_batch(batch, w["input_channels"], 128, 512, 42, 1234 + rank, dev)
+    x, target = T.synthetic_batch(batch, w["input_channels"], args.freq, 512, 42, 1234 + rank, dev)
 
     def eager_step():
         return DP.dp_train_step(model, opt, sync, x, target, 42, T.seld_loss_fn)
@@ -261,7 +266,7 @@ def main():
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm, "ms_per_step": round(ms, 3),
             "ms_per_step_median": round(statistics.median(per_step), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {w['name']} train step, F=128 T=512 (U=L={w['U']}, SURVEY F3), "
+            "config": {"workload": f"{args.workload}: {w['name']} train step, F={args.freq} T=512 (U=L={w['U'] * (args.freq // 128)}, SURVEY F3), "
                                    f"batch {batch}/GPU, random-init weights", "global_batch": batch * world,
                        "parallelism": f"dp{world}", "step_mode": step_mode},
             "loss": round(final_loss, 6),
@@ -315,7 +320,7 @@ def main():
             per.sort(key=lambda r: -r["ms_per_step"])
             out["conv_kernels"] = per[:8]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
+            out["cpu_baseline"] = cpu_baseline(w, args.freq)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
