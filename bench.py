@@ -49,7 +49,13 @@ WORKLOADS = {
 }
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense
-FIRST_LAYER_KERNEL = "hc_conv_smallk_kernel"     # cnn.0 forward: the one HBM-bound DualQ-Conv
+# cnn.0 forward, the one HBM-bound DualQ-Conv: the fast-product kernel with 1 or 2 block channels per K chunk
+# (only the networks' first layers have so few), or the block-matrix short-K kernel when that path is forced
+FIRST_LAYER_KERNELS = ("hcq_conv_kernel<3, 3, 1,", "hcq_conv_kernel<3, 3, 2,", "hc_conv_smallk_kernel")
+
+
+def first_layer_label(labels):
+    return next((k for k in labels if k.startswith(FIRST_LAYER_KERNELS)), None)
 
 
 def model_kwargs(w, freq=128, time_dim=512):
@@ -250,7 +256,7 @@ def main():
     # ---- roofline pass: the same step, eager, only the dominant kernel and the first-layer DualQ-Conv bracketed
     summ = {}
     if timing and dominant and args.roofline_steps > 0:
-        first = next((k for k in survey if k.startswith(FIRST_LAYER_KERNEL)), None)
+        first = first_layer_label(survey)
         H.kernel_timer.only = {dominant} | ({first} if first else set())
         H.kernel_timer.active = True
         for _ in range(args.roofline_steps):
@@ -305,7 +311,7 @@ def main():
                 return roof, d
             if dominant in summ:
                 out["roofline"], _ = roofline(dominant)
-            first = next((k for k in summ if k.startswith(FIRST_LAYER_KERNEL)), None)
+            first = first_layer_label(summ)
             if first and first != dominant:
                 # the north-star's own target shape (first-layer DualQ-Conv forward), priced against HBM whatever the
                 # formula above says: AI 26 puts it next to the ridge (19.7 flop/B)

@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     constexpr int TAPS = KH * KW;
     constexpr int NT = NT1 + NT2;
     constexpr int KQ = IBC * TAPS;
-    static_assert(KQ % 4 == 0, "a K chunk is a whole number of k-groups");
-    constexpr int NG = KQ / 4;
+    constexpr int NG = (KQ + 3) / 4;                  // the first layers (1 or 2 block channels x 9 taps) pad the last k-group:
+                                                      // packed weights are zero there, the lane re-reads k = 0
     constexpr int NPAIR = (NG + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     int aoff[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const int kq = 4 * g + fk;
+        const int kq = (4 * g + fk) < KQ ? 4 * g + fk : 0;
         const int ibl = kq / TAPS;
         const int tap = kq - ibl * TAPS;
         const int kh = tap / KW;
@@ -430,6 +430,7 @@ __device__ __forceinline__ float hcq_pack_value(const HcqPackP& p, long long idx
     const int g = 2 * j + gg;
     if (g >= p.NG) return 0.f;
     const int kq = 4 * g + k;
+    if (kq >= p.IBC * p.taps) return 0.f;                  // padding of the last k-group
     const int tf = range ? p.NT1 + t : t;                  // tile (accumulator slot) of the workgroup
     const int ds = mix ? 2 : tf;                           // descriptor slot: a mixed workgroup's slot NT1 is the mixed
     const int grp = n >> 3;                                // tile, its other slots are padding
@@ -522,7 +523,7 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
     const int dpad = KW == 3 ? (dil + 3) / 4 * 4 : 0;
     const int wext = 64 + 2 * dpad;
     // K chunk: candidates in order of preference; two workgroups per CU must fit (78 KB each)
-    static const int cand11[] = {16, 24, 8, 0}, cand13[] = {8, 4, 0}, cand33[] = {4, 0};
+    static const int cand11[] = {16, 24, 8, 0}, cand13[] = {8, 4, 0}, cand33[] = {4, 2, 1, 0};
     const int* cand = taps == 1 ? cand11 : (taps == 3 ? cand13 : cand33);
     int IBC = 0;
     size_t smem = 0;
@@ -533,6 +534,12 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
         if (need <= 78 * 1024) { IBC = cand[i]; smem = need; break; }
     }
     if (!IBC) return pl;
+    // The 8-channel dual-quaternion first layer (ONE block channel: 9 of 12 k-slots used, 120 MFMAs per workgroup) stays on
+    // the persistent short-K kernel hc_conv_smallk_kernel<12,3,3,4,18,9>: 609 us against 688 here at batch 32, 283 / 326
+    // at 16 (the two-workgroup channel split: 797).  Two block channels already win: 443 against 1303 (config 4's 16-channel
+    // layer, which does not fit that kernel's LDS), 227 against 342 for config 2's quaternion layer.
+    if (mode == 0 && taps == 9 && A == 8 && IB == 1 && Cdst == 192 && (long long)d->N * Himg * W >= 256 * 128 &&
+        !env().conv_no_smallk) return pl;
     const int rows = A * IBC * KH;
     const int items = rows * (wext / 4);
     const int XI = (items + 255) / 256;
@@ -573,7 +580,7 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
         else return pl;
         for (int t = 0; t < NT1; ++t) { k.tile_ob[t][0] = 16 * t; k.tile_ob[t][1] = 16 * t + 8; }
     }
-    const int NG = IBC * taps / 4, NPAIR = (NG + 1) / 2;
+    const int NG = (IBC * taps + 3) / 4, NPAIR = (NG + 1) / 2;
     const int NT = NT1 + NT2;
     k.A = A; k.N = d->N; k.Csrc = Csrc; k.Cdst = Cdst; k.IB = IB; k.OB = OB;
     k.W = W; k.Himg = Himg; k.dil = dil; k.dpad = dpad; k.wext = wext; k.nch = IB / IBC;
@@ -614,6 +621,8 @@ static int hcq_pick(const HcqPlan& pl, HcqKern* k) {
     else if (pl.KH == 1 && pl.KW == 1 && pl.IBC == 24) { xi8 = 12; xi4 = 6; }
     else if (pl.KH == 1 && pl.KW == 1 && pl.IBC == 8) { xi8 = 4; xi4 = 2; }
     else if (pl.KH == 3 && pl.KW == 3 && pl.IBC == 4) { xi8 = 7; xi4 = 4; }
+    else if (pl.KH == 3 && pl.KW == 3 && pl.IBC == 2) { xi8 = 4; xi4 = 2; }
+    else if (pl.KH == 3 && pl.KW == 3 && pl.IBC == 1) { xi8 = 2; xi4 = 1; }
     else return 0;
     const int xi = pl.NR == 2 ? xi8 : xi4;
     if (pl.XI > xi) return 0;
@@ -659,6 +668,8 @@ static int hcq_launch(const HcqPlan& pl, hipStream_t st) {
     if (k.KH == 1 && k.IBC == 16) return hcq_launch_cfg<1, 1, 16, 8, 4>(pl, k, st);
     if (k.KH == 1 && k.IBC == 24) return hcq_launch_cfg<1, 1, 24, 12, 6>(pl, k, st);
     if (k.KH == 1 && k.IBC == 8) return hcq_launch_cfg<1, 1, 8, 4, 2>(pl, k, st);
+    if (k.IBC == 2) return hcq_launch_cfg<3, 3, 2, 4, 2>(pl, k, st);
+    if (k.IBC == 1) return hcq_launch_cfg<3, 3, 1, 2, 1>(pl, k, st);
     return hcq_launch_cfg<3, 3, 4, 7, 4>(pl, k, st);
 }
 

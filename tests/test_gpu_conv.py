@@ -382,6 +382,39 @@ def test_hcq_conv_vs_oracle(algebra, shape, cout, k, pad, dil):
     _close(y3, ref2 + (yr.detach() - bias.double().view(1, -1, *([1] * (yr.dim() - 2)))))
 
 
+@pytest.mark.parametrize("algebra,shape,cout", [
+    (8, (2, 8, 6, 128), 192),        # the 8-channel first layer: 1 block channel x 9 taps = 9 of 12 k-slots (at the
+                                     # benchmark's size this layer stays on hc_conv_smallk_kernel: hcq_plan)
+    (8, (2, 16, 5, 64), 192),        # the 16-channel (mag + phase) first layer: K = 144 -> 18 of 20
+    (4, (2, 8, 4, 64), 64),          # quaternion first layer (config 2): 2 block channels
+    (8, (1, 48, 3, 64), 128),        # 6 block channels: three chunks of two
+    (4, (3, 12, 2, 128), 128),       # 3 block channels: three chunks of one
+])
+def test_hcq_forward_with_padded_k_groups(algebra, shape, cout):
+    """3x3 layers whose input has fewer than 4 block channels per K chunk (the networks' first layers): the last k-group
+    of a chunk is padded (zero packed weights, csrc/hcq_conv.hip).  Forward + BatchNorm statistics against the oracle."""
+    import seld_amd
+    H, L = seld_amd.hip_ops, seld_amd._lib
+    desc = H.make_conv_desc(tuple(shape), cout, algebra, (3, 3), 1, 1, 1)
+    assert H.hcq_label(desc, 0).startswith("hcq_conv_kernel<3, 3, ")
+    gen = torch.Generator().manual_seed(78)
+    x = torch.randn(shape, generator=gen)
+    wshape = (cout // algebra, shape[1] // algebra, 3, 3)
+    ws = [torch.randn(wshape, generator=gen) * 0.2 for _ in range(algebra)]
+    bias = torch.randn(cout, generator=gen)
+    dev = torch.device("cuda:0")
+    wd = [w.to(dev) for w in ws]
+    stats_rep = H.new_stats(cout, dev)
+    y = H.conv_fwd(desc, x.to(dev), wd, bias.to(dev), epilogue=L.SELD_EPI_STATS, stats=stats_rep)
+    yr = O.hypercomplex_conv(x.double(), [w.double() for w in ws], bias.double(), 1, 1, 1, 1, mode="explicit")
+    _close(y, yr)
+    stats = stats_rep.view(H.STATS_REPLICAS, 2 * cout).sum(0).double().cpu()
+    assert torch.allclose(stats[:cout], yr.sum(dim=(0, 2, 3)), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(stats[cout:], (yr ** 2).sum(dim=(0, 2, 3)), rtol=1e-4, atol=2e-3)
+    y0 = H.conv_fwd(desc, x.to(dev), wd)                       # plain epilogue
+    _close(y0, yr - bias.double().view(1, -1, 1, 1))
+
+
 @pytest.mark.parametrize("algebra,shape,cout,k,pad,dil", [c for c in HCQ_CASES if c[0] == 8][:5] + [HCQ_CASES[7], HCQ_CASES[8]])
 def test_hcq_pair_matches_two_single_calls(algebra, shape, cout, k, pad, dil):
     """Two convolutions of one input in one launch (forward) and the sum of their data gradients in one launch, on the

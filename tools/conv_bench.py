@@ -14,6 +14,9 @@ import seld_amd  # noqa: E402
 H = seld_amd.hip_ops
 SHAPES = {
     "cnn0": dict(x=(32, 8, 128, 512), cout=192, k=(3, 3), pad=1, dil=1),
+    "cnn0_16ch": dict(x=(16, 16, 128, 512), cout=192, k=(3, 3), pad=1, dil=1),                 # config 4, 16 samples / GPU
+    "cnn0_q": dict(x=(32, 8, 128, 512), cout=64, k=(3, 3), pad=1, dil=1, algebra=4),            # config 2
+    "cnn0_b16": dict(x=(16, 8, 128, 512), cout=192, k=(3, 3), pad=1, dil=1),                   # config 5, one stream
     "cnn1": dict(x=(32, 192, 16, 512), cout=192, k=(3, 3), pad=1, dil=1),
     "cnn2": dict(x=(32, 192, 2, 512), cout=192, k=(3, 3), pad=1, dil=1),
     "tcn_k3": dict(x=(32, 192, 512), cout=384, k=(3,), pad=5, dil=5),
