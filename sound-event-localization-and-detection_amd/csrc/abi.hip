@@ -37,7 +37,7 @@ static void load_env_locked() {
     e.wgrad_norow = flag("SELD_WGRAD_NOROW");
     e.wgrad_slow = flag("SELD_WGRAD_SLOW");
     e.mha_no_mfma = flag("SELD_MHA_NO_MFMA");
-    e.wgrad_cfg = (int)bounded("SELD_WGRAD_CFG", 0, 4, -1);
+    e.wgrad_cfg = (int)bounded("SELD_WGRAD_CFG", 0, 5, -1);
     e.wgrad_wgs = bounded("SELD_WGRAD_WGS", 1, 1 << 20, 0);
     e.smallk_wgs = bounded("SELD_SMALLK_WGS", 1, 1 << 20, 0);
 #ifdef SELD_TUNING

@@ -448,8 +448,8 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, Wgrad
         const long long nz = nt - ((Ktot / 2) + bn - 1) / bn;          // column tiles entirely in the upper K half
         if (nz > 0 && mz > 0) { p->mz = (int)mz; p->nact = (int)(nt - nz); tiles -= mz * nz; }
     }
-    // resident workgroups per CU (LDS-limited): 128x128 / 192x80 / 96x128 -> 2, 64x80 -> 3, 64x64 -> 4
-    long long slots = (bm == 64 ? (bn == 64 ? 4 : 3) : 2) * 256;
+    // resident workgroups per CU (LDS-limited): 128x128 / 192x80 / 96x128 / 64x160 -> 2, 64x80 -> 3, 64x64 -> 4
+    long long slots = (bm == 64 ? (bn == 64 ? 4 : (bn == 80 ? 3 : 2)) : 2) * 256;
     if (env().wgrad_wgs) slots = env().wgrad_wgs;
     tiles *= (p->nslots > 1 ? 2 : 1);                     // a pair launch carries two gradients
     long long want = slots / tiles;                       // floor: stay within one generation
@@ -466,11 +466,14 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, Wgrad
 }
 
 // tile configuration: 0 = 128 x 128 (waves 2 x 2), 1 = 192 x 80 for short K (first layer), 2 = 64 x 64 (small layers),
-// 3 = 96 x 128, 4 = 64 x 80 (short K: a third of the float-atomic chain per gradient element of 192 x 80, x re-read 3x)
+// 3 = 96 x 128, 4 = 64 x 80 (short K: a third of the float-atomic chain per gradient element of 192 x 80, x re-read 3x),
+// 5 = 64 x 160 (the 16-channel first layer, K = 144: ONE column tile, so the 0.8-1.6 GB dy / y operand is read once --
+// with 64 x 64 tiles it was read three times: 744 us at batch 16)
 static int wgrad_cfg(const seld_conv_desc* d) {
     const int Ktot = d->Cin * d->k[0] * d->k[1];
-    if (env().wgrad_cfg >= 0) return env().wgrad_cfg;     // tuning aid, validated 0..4
+    if (env().wgrad_cfg >= 0) return env().wgrad_cfg;     // tuning aid, validated 0..5
     if (Ktot <= 80 && d->Cout > 64) return (d->Cout % 64 == 0) ? 4 : 1;
+    if (Ktot <= 160 && d->Cout > 64 && d->Cout % 64 == 0) return 5;
     if (d->Cout <= 64 || Ktot <= 64) return 2;
     // few 128 x 128 tiles and a short reduction (positions / 512 splits at most): take 64 x 64 tiles so that
     // the launch still has >= 2 workgroups per CU
@@ -551,7 +554,7 @@ static int wgrad_run2(const seld_conv_desc* d, const float* x, const float* dy, 
         }
     }
     const int cfg = wgrad_cfg(d);
-    static const int tile_m[5] = {128, 192, 64, 96, 64}, tile_n[5] = {128, 80, 64, 128, 80};
+    static const int tile_m[6] = {128, 192, 64, 96, 64, 64}, tile_n[6] = {128, 80, 64, 128, 80, 160};
     p.nsplit = wgrad_splits(d, o, tile_m[cfg], tile_n[cfg], &p);
     if (hc_wgrad_row_ok(p)) hc_wgrad_row_launch(p, cfg, st);           // row-chunk staging (hc_wgrad_row.hip)
     else if (dy2) return SELD_EUNSUPPORTED;                            // pairs only on the row kernel
@@ -559,6 +562,7 @@ static int wgrad_run2(const seld_conv_desc* d, const float* x, const float* dy, 
     else if (cfg == 1) launch_wgrad<4, 3, 5>(p, st);
     else if (cfg == 3) launch_wgrad<2, 3, 4>(p, st);
     else if (cfg == 4) launch_wgrad<4, 1, 5>(p, st);
+    else if (cfg == 5) launch_wgrad<4, 1, 10>(p, st);
     else launch_wgrad<2, 2, 2>(p, st);
     rc = check_launch();
     if (rc) return rc;
@@ -592,7 +596,7 @@ int hc_wgrad_label(const seld_conv_desc* d, char* buf, int buflen) {
     int kh = d->k[0], kw = d->k[1];
     if (!((kh == 1 && kw == 1) || (kh == 1 && kw == 3) || (kh == 3 && kw == 3))) kh = kw = 0;
     const int cfg = wgrad_cfg(d);
-    const char* t = cfg == 0 ? "2, 4, 4" : (cfg == 1 ? "4, 3, 5" : (cfg == 3 ? "2, 3, 4" : (cfg == 4 ? "4, 1, 5" : "2, 2, 2")));
+    const char* t = cfg == 0 ? "2, 4, 4" : (cfg == 1 ? "4, 3, 5" : (cfg == 3 ? "2, 3, 4" : (cfg == 4 ? "4, 1, 5" : (cfg == 5 ? "4, 1, 10" : "2, 2, 2"))));
     int o[2];
     hc_out_shape(d, o);
     const bool fast = (o[1] % 4 == 0) && o[1] >= 32 && d->stride[1] == 1 && !env().wgrad_slow;
@@ -635,7 +639,7 @@ extern "C" int seld_hc_conv_bwd_weight_bnpool_acc(const seld_conv_desc* d, const
     p.pooled = pooled; p.dpooled = dpooled; p.pidx = idx; p.coef = coef; p.poolh = ph;
     for (int i = 0; i < 8; ++i) p.gw.p[i] = (i < d->algebra) ? dw[i] : nullptr;
     const int cfg = wgrad_cfg(d);
-    static const int tile_m[5] = {128, 192, 64, 96, 64}, tile_n[5] = {128, 80, 64, 128, 80};
+    static const int tile_m[6] = {128, 192, 64, 96, 64, 64}, tile_n[6] = {128, 80, 64, 128, 80, 160};
     p.nsplit = wgrad_splits(d, o, tile_m[cfg], tile_n[cfg], &p);
     if (!hc_wgrad_row_ok(p)) return SELD_EUNSUPPORTED;
     hc_wgrad_row_launch(p, cfg, (hipStream_t)stream);

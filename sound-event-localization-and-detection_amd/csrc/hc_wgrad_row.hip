@@ -307,7 +307,7 @@ static void launch_row(const WgradP& p, hipStream_t st) {
     else hipLaunchKernelGGL((hc_wgrad_row_kernel<WRW, RT, CTL, 1, 1, 0>), grid, dim3(256), 0, st, p);
 }
 
-// cfg as in wgrad_cfg(): 0 = 128 x 128, 1 = 192 x 80, 2 = 64 x 64, 3 = 96 x 128, 4 = 64 x 80
+// cfg as in wgrad_cfg(): 0 = 128 x 128, 1 = 192 x 80, 2 = 64 x 64, 3 = 96 x 128, 4 = 64 x 80, 5 = 64 x 160
 void hc_wgrad_row_launch(const WgradP& p_in, int cfg, hipStream_t st) {
     WgradP p = p_in;
     p.dbg = env().wgrad_dbg;            // non-zero only in -DSELD_TUNING builds (timing experiments, wrong results)
@@ -315,6 +315,7 @@ void hc_wgrad_row_launch(const WgradP& p_in, int cfg, hipStream_t st) {
     else if (cfg == 1) launch_row<4, 3, 5>(p, st);
     else if (cfg == 3) launch_row<2, 3, 4>(p, st);
     else if (cfg == 4) launch_row<4, 1, 5>(p, st);
+    else if (cfg == 5) launch_row<4, 1, 10>(p, st);
     else launch_row<2, 2, 2>(p, st);
 }
 
