@@ -156,7 +156,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--freq", type=int, default=128, choices=[128, 256],
                     help="frequency bins of the input: 128 = the shape the metric is quoted on, 256 = config-exact")
-    ap.add_argument("--mode", default=os.environ.get("SELD_BENCH_MODE", "graph"), choices=["graph", "eager"])
+    ap.add_argument("--mode", default=os.environ.get("SELD_BENCH_MODE", "auto"), choices=["auto", "graph", "eager"],
+                    help="how the step is issued: one recorded HIP graph per step, eager launches, or (auto) whichever of "
+                         "the two was faster over a few untimed steps after the warm-up -- same kernels, same work")
     ap.add_argument("--roofline-steps", type=int, default=5, help="instrumented eager steps after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -218,9 +220,9 @@ def main():
             os.environ["SELD_WGRAD_SIDE_STREAM"] = side_env
     dominant = max(survey, key=lambda k: survey[k]["ms"]) if survey else None
 
-    step_mode = args.mode
+    step_mode = "eager" if args.mode == "eager" else "graph"
     step = eager_step
-    if args.mode == "graph":
+    if args.mode in ("graph", "auto"):
         try:
             runner = T.GraphedTrainStep(model, opt, x, target, 42, 1.0, 5.0, sync=sync, warmup=1)
             runner()                # one replay outside the timed region
@@ -230,6 +232,24 @@ def main():
             step_mode = f"eager (graph recording failed: {type(exc).__name__}: {str(exc)[:120]})"
             if rank == 0:
                 print("bench: " + step_mode, file=sys.stderr)
+    if args.mode == "auto" and step is not eager_step:
+        # both issue the same kernels; which one is faster depends on how fast this host launches (eager) against
+        # what the graph replay costs: 6 untimed steps each, rank 0 decides for everybody
+        def probe(fn, n=6):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        t_graph, t_eager = probe(step), probe(eager_step)
+        pick = torch.tensor([1.0 if t_eager < t_graph else 0.0], device=dev)
+        if world > 1:
+            torch.distributed.broadcast(pick, 0)
+        if pick.item() > 0.5:
+            step, step_mode = eager_step, "eager"
+        step_mode += f" (auto: probe {t_graph * 1e3:.2f} ms recorded / {t_eager * 1e3:.2f} ms eager per step)"
 
     # ---- timed region: exactly K steps between barrier + synchronize; an event after every step gives the per-step
     # times (median) without a host synchronisation inside the region
