@@ -380,6 +380,231 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// First layers (3x3, one or two input block channels): the K loop is ONE short chunk (9 or 18 k of 12 / 20 slots), so
+// hcq_conv_kernel above is all prologue and epilogue there (120 MFMAs per workgroup: 688 us for the 8-channel layer at
+// batch 32, the block-matrix short-K kernel takes 609).  Here a workgroup keeps its 64 columns and walks R consecutive
+// image rows: the R + 2 input rows are staged once (23 / 46 KB), there is ONE barrier, the weight fragments of row r+1
+// are requested under the MFMAs of row r, a row's stores drain under the next row's MFMAs and the BatchNorm statistics
+// stay in registers until the last row.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int IBC, int NT1, int NT2, int NR, int R>
+__global__ __launch_bounds__(256, 2) void hcq_first_kernel(const HcqP p) {
+    constexpr int KH = 3, KW = 3, TAPS = 9;
+    constexpr int NT = NT1 + NT2;
+    constexpr int KQ = IBC * TAPS;
+    constexpr int NG = (KQ + 3) / 4;
+    constexpr int NPAIR = (NG + 1) / 2;
+    constexpr int NPC = NR * NPAIR;
+    constexpr int XR = R + KH - 1;                    // staged input rows
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int A = p.A;
+    constexpr int wext = 72, qw = wext >> 2, DPAD = 4;    // dilation 1: halo of 4 each side (the host checks p.wext)
+
+    const unsigned tiles_per_row = (unsigned)p.W >> 6;
+    const unsigned hblocks = (unsigned)p.Himg / R;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give an XCD consecutive tiles, so that the
+    // 64-column pieces of one 2 KB image row are written back by ONE L2 (spread over eight, every piece was a separate
+    // 256-byte DRAM write)
+    unsigned b = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) b = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int w0 = (int)(b % tiles_per_row) * 64;
+    b /= tiles_per_row;
+    const int h0 = (int)(b % hblocks) * R;
+    const int n_img = (int)(b / hblocks);
+
+    // ---- stage the R + 2 rows of every (component, block channel) once -------------------------------------------
+    const unsigned S = (unsigned)(p.Himg * p.W);
+    {
+        const unsigned src_bytes = (unsigned)p.N * (unsigned)p.Csrc * S * 4u;
+        const unsigned OOB = 0xFFFFFFF0u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, src_bytes, 0x00020000);
+        const int items = A * IBC * XR * qw;
+        const unsigned img_base = (unsigned)n_img * (unsigned)p.Csrc * S;
+        constexpr float inv_qw = 1.0f / (float)qw;
+        for (int f = tid; f < items; f += 256) {
+            const int row = small_div_h(f, inv_qw);               // (comp * IBC + ibl) * XR + xr
+            const int quad = f - row * qw;
+            const int ci = row / XR;
+            const int xr = row - ci * XR;
+            const int comp = ci / IBC;
+            const int ibl = ci - comp * IBC;
+            const int hh = h0 - (KH - 1) / 2 + xr;
+            const int ww = w0 - DPAD + 4 * quad;
+            const bool ok = (unsigned)hh < (unsigned)p.Himg && (unsigned)ww < (unsigned)p.W;
+            const unsigned e = img_base + ((unsigned)(comp * p.IB + ibl) * (unsigned)p.Himg + (unsigned)hh) * (unsigned)p.W + (unsigned)ww;
+            const uintx4h v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? e * 4u : OOB, 0, 0);
+            *reinterpret_cast<float4*>(lds + (row * qw + quad) * 4) =
+                make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    }
+
+    int aoff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int kq = (4 * g + fk) < KQ ? 4 * g + fk : 0;
+        const int ibl = kq / TAPS;
+        const int tap = kq - ibl * TAPS;
+        const int kh = tap / KW;
+        const int kw = tap - kh * KW;
+        aoff[g] = (ibl * XR + kh) * wext + DPAD + wave * 16 + fr + (kw - (KW - 1) / 2);
+    }
+    constexpr int comp_stride = IBC * XR * wext;
+    const float* const wbase = p.wpack;                 // one channel tile, one weight set, one chunk
+
+    float2 bfr[8][NT];
+    float gm[2][8];
+    float raw[4];
+    auto load_b1 = [&](const float* blk, int j, int m, auto ntrc) __attribute__((always_inline)) {
+        constexpr int NTR = decltype(ntrc)::value;
+        const float* q = blk + ((long long)(j * 8 + m) * 64 + lane) * (2 * NTR);
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) bfr[m][t] = *reinterpret_cast<const float2*>(q + 2 * t);
+    };
+    auto read_raw = [&](const float* xs, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[q] = xs[aoff[g] + q * comp_stride];
+    };
+    using INT = std::integral_constant<int, NT>;
+    using INT2 = std::integral_constant<int, NT2>;
+
+    float* const dst = p.dst[0];
+    const float* const bias = p.bias[0];
+    const int epi = p.epilogue[0];
+    const int grp = fr >> 3;
+    const unsigned img_off = (unsigned)n_img * (unsigned)p.Cdst * S;
+    // BatchNorm statistics: one slot per (wave, tile, component, LANE) behind the staged rows, read-modify-written row by
+    // row by its owner (24 more registers per lane would spill; LDS float atomics doubled the kernel's time)
+    float* const sbuf = lds + A * IBC * XR * wext;
+    const bool want_stats = (epi & SELD_EPI_STATS) != 0;
+    if (want_stats)
+        for (int e = tid; e < 4 * NT * 4 * 64 * 2; e += 256) sbuf[e] = 0.f;
+    int chbase[NT];                                     // first-component channel of this lane in tile t, -1: padding
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ob0 = p.tile_ob[t][grp];
+        chbase[t] = ob0 >= 0 ? p.tile_half[t][grp] * 4 * p.OB + ob0 + (fr & 7) : -1;
+    }
+
+#pragma unroll
+    for (int m = 0; m < 8; ++m) load_b1(wbase, 0, m, INT{});
+    __syncthreads();
+
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        floatx4 acc[NT][8];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc[t][m] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        const bool more = r + 1 < R;
+        // the fragments are the same for every row: without this the compiler hoists all 160 registers of them out of
+        // the row loop (414 VGPRs wanted)
+        const float* wrow = wbase;
+        asm volatile("" : "+s"(wrow));
+        const float* xs0 = lds + r * wext + p.half_src[0] * 4 * comp_stride;
+        const float* xs1 = lds + r * wext + p.half_src[1] * 4 * comp_stride;
+        read_raw(xs0, 0);
+        xforms(raw, gm[0]);
+#pragma unroll
+        for (int s = 0; s < NR * NG; ++s) {
+            const int rr = s / NG, g = s - rr * NG;
+            const int pc = rr * NPAIR + g / 2;
+            const int gst = s & 1;
+            const bool last = s + 1 == NR * NG;
+            const bool pair_ends = (g & 1) == 1 || g + 1 == NG;
+            if (!last) {
+                const int rn = (s + 1) / NG, gn = (s + 1) - rn * NG;
+                read_raw(rn == 0 ? xs0 : xs1, gn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (rr == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gm[gst][m], (g & 1) ? bfr[m][t].y : bfr[m][t].x,
+                                                                          acc[t][m], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT2; ++t)
+                        acc[NT1 + t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gm[gst][m], (g & 1) ? bfr[m][t].y : bfr[m][t].x,
+                                                                                acc[NT1 + t][m], 0, 0, 0);
+                }
+                if (pair_ends) {
+                    const int pn = pc + 1;
+                    if (pn < NPC) {
+                        const int rn = pn / NPAIR, jn = pn - rn * NPAIR;
+                        if (rn == 0) load_b1(wrow, jn, m, INT{});
+                        else load_b1(wrow + p.range_stride[0], jn, m, INT2{});
+                    } else if (more) {
+                        load_b1(wrow, 0, m, INT{});               // the next row starts with the same fragments
+                    }
+                }
+            }
+            if (!last) xforms(raw, gm[gst ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- this row's results ------------------------------------------------------------------------------------
+        const unsigned pos_off = (unsigned)(h0 + r) * (unsigned)p.W + (unsigned)(w0 + wave * 16 + fk * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            floatx4 c[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h0_ = 0.5f * acc[t][0][e], h1 = 0.5f * acc[t][1][e], h2 = 0.5f * acc[t][2][e], h3 = 0.5f * acc[t][3][e];
+                c[0][e] = (h3 - h0_) + (h1 + h2) + acc[t][4][e];
+                c[1][e] = (h3 - h0_) - (h1 + h2) + acc[t][5][e];
+                c[2][e] = (h3 + h0_) + (h2 - h1) + acc[t][6][e];
+                c[3][e] = (h3 + h0_) + (h1 - h2) - acc[t][7][e];
+            }
+            if (chbase[t] >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int chn = chbase[t] + q * p.OB;
+                    const float bq = bias ? bias[chn] : 0.f;
+                    const float4 o = make_float4(c[q][0] + bq, c[q][1] + bq, c[q][2] + bq, c[q][3] + bq);
+                    *reinterpret_cast<float4*>(dst + img_off + (unsigned)chn * S + pos_off) = o;
+                    if (want_stats) {
+                        const int slot = ((wave * NT + t) * 4 + q) * 64 + lane;
+                        sbuf[slot] += (o.x + o.y) + (o.z + o.w);                       // the slot is this lane's own
+                        sbuf[4 * NT * 4 * 64 + slot] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);           // one tile's recombination at a time (registers)
+        }
+    }
+
+    if (want_stats) {
+        __syncthreads();
+        float* rep = p.stats[0] + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
+        for (int e = tid; e < NT * 4 * 16; e += 256) {
+            const int fr_ = e & 15, q = (e >> 4) & 3, t = e >> 6;
+            const int g_ = fr_ >> 3;
+            const int ob0 = p.tile_ob[t][g_];
+            if (ob0 < 0) continue;
+            const int chn = (p.tile_half[t][g_] * 4 + q) * p.OB + ob0 + (fr_ & 7);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int slot = ((wv * NT + t) * 4 + q) * 64 + k4 * 16 + fr_;
+                    a1 += sbuf[slot];
+                    a2 += sbuf[4 * NT * 4 * 64 + slot];
+                }
+            atomicAdd(rep + chn, a1);
+            atomicAdd(rep + p.Cdst + chn, a2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Weight forms in fragment order.  One thread per packed float.
 //   mode 0 (forward):        dst block channel = conv output block channel, K runs over (conv input block channel, tap)
 //   mode 1 (data gradient):  dst = conv INPUT block channel, K over (conv output block channel, flipped tap), conjugate
@@ -491,6 +716,7 @@ __global__ __launch_bounds__(256) void hcq_pack_table_kernel(const HcqPackP* __r
 struct HcqPlan {
     int ok;
     int KH, KW, IBC, NT1, NT2, NR, XI, mix;
+    int first_rows;              // > 0: hcq_first_kernel walks this many image rows per workgroup
     HcqP kp;
     HcqPackP pp;
     size_t pack_floats;
@@ -534,10 +760,11 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
         if (need <= 78 * 1024) { IBC = cand[i]; smem = need; break; }
     }
     if (!IBC) return pl;
-    // The 8-channel dual-quaternion first layer (ONE block channel: 9 of 12 k-slots used, 120 MFMAs per workgroup) stays on
-    // the persistent short-K kernel hc_conv_smallk_kernel<12,3,3,4,18,9>: 609 us against 688 here at batch 32, 283 / 326
-    // at 16 (the two-workgroup channel split: 797).  Two block channels already win: 443 against 1303 (config 4's 16-channel
-    // layer, which does not fit that kernel's LDS), 227 against 342 for config 2's quaternion layer.
+    // The 8-channel dual-quaternion first layer (ONE block channel: 9 of 12 k-slots used) stays on the persistent short-K
+    // kernel hc_conv_smallk_kernel<12,3,3,4,18,9>: 610 us (530 inside the step) against 629 (571) for hcq_first_kernel
+    // and 688 for hcq_conv_kernel at batch 32; 280 / 287 / 326 at 16.  With two block channels the fast product wins:
+    // config 4's 16-channel layer (which does not fit that kernel's LDS) 1303 -> 405 us, config 2's quaternion layer
+    // 342 -> 225.
     if (mode == 0 && taps == 9 && A == 8 && IB == 1 && Cdst == 192 && (long long)d->N * Himg * W >= 256 * 128 &&
         !env().conv_no_smallk) return pl;
     const int rows = A * IBC * KH;
@@ -604,6 +831,14 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
     const long long ptot = (long long)d->N * Himg * W;
     pl.grid = dim3((unsigned)(ptot / 64), (unsigned)(k.ytiles * nsets), 1);
     pl.smem = smem;
+    // first layers: one chunk, one channel tile, one weight set -> the row-walking kernel
+    constexpr int FIRST_R = 8;
+    if (mode == 0 && taps == 9 && IBC == IB && IB <= 2 && k.ytiles == 1 && nsets == 1 && !mix && Himg % FIRST_R == 0 && wext == 72 &&
+        !env().hcq_no_first) {
+        pl.first_rows = FIRST_R;
+        pl.grid = dim3((unsigned)(ptot / 64 / FIRST_R), 1, 1);
+        pl.smem = ((size_t)A * IBC * (FIRST_R + 2) * wext + 4 * NT * 4 * 64 * 2) * sizeof(float);   // rows + statistics slots
+    }
     pl.ok = 1;
     return pl;
 }
@@ -652,9 +887,35 @@ static int hcq_launch_cfg(const HcqPlan& pl, const HcqKern& k, hipStream_t st) {
                       : hcq_launch_one<KH, KW, IBC, 1, 0, 1, XI4>(pl, st);
 }
 
+template <int IBC, int NT1, int NT2, int NR>
+static int hcq_launch_first(const HcqPlan& pl, hipStream_t st) {
+    auto kern = hcq_first_kernel<IBC, NT1, NT2, NR, 8>;
+    if (pl.smem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem) != hipSuccess)
+        return SELD_ELAUNCH;
+    hipLaunchKernelGGL(kern, pl.grid, dim3(256), pl.smem, st, pl.kp);
+    return check_launch();
+}
+
+// The row-walking first-layer kernel takes no addend / accumulate epilogue (the first layer has none).
+static bool hcq_first_takes(const HcqPlan& pl) {
+    if (!pl.first_rows || pl.first_rows != 8) return false;
+    if (pl.kp.epilogue[0] & ~SELD_EPI_STATS) return false;
+    if (pl.NR == 2) return pl.NT1 == 1 && (pl.NT2 == 2 || pl.NT2 == 1);
+    return pl.NT2 == 0 && (pl.NT1 == 1 || pl.NT1 == 2);
+}
+
 static int hcq_launch(const HcqPlan& pl, hipStream_t st) {
     HcqKern k;
     if (!hcq_pick(pl, &k)) return SELD_EUNSUPPORTED;
+    if (hcq_first_takes(pl)) {
+        if (k.IBC == 1) {
+            if (k.NR == 2) return k.NT2 == 2 ? hcq_launch_first<1, 1, 2, 2>(pl, st) : hcq_launch_first<1, 1, 1, 2>(pl, st);
+            return k.NT1 == 2 ? hcq_launch_first<1, 2, 0, 1>(pl, st) : hcq_launch_first<1, 1, 0, 1>(pl, st);
+        }
+        if (k.NR == 2) return k.NT2 == 2 ? hcq_launch_first<2, 1, 2, 2>(pl, st) : hcq_launch_first<2, 1, 1, 2>(pl, st);
+        return k.NT1 == 2 ? hcq_launch_first<2, 2, 0, 1>(pl, st) : hcq_launch_first<2, 1, 0, 1>(pl, st);
+    }
     if (k.KW == 3 && k.KH == 1 && k.IBC == 8) {
         if (k.NR == 2) {
             if (k.XI == 5) return hcq_launch_cfg<1, 3, 8, 5, 3>(pl, k, st);
@@ -693,7 +954,10 @@ extern "C" int seld_hcq_kernel_label(const seld_conv_desc* d, int32_t mode, int3
     const HcqPlan pl = hcq_plan(d, mode, npair);
     HcqKern k;
     if (!pl.ok || !hcq_pick(pl, &k)) return SELD_EUNSUPPORTED;
-    snprintf(buf, buflen, "hcq_conv_kernel<%d, %d, %d, %d, %d, %d, %d>", k.KH, k.KW, k.IBC, k.NT1, k.NT2, k.NR, k.XI);
+    if (pl.first_rows && hcq_first_takes(pl))        // (label of the plain / statistics epilogue: what the first layer runs)
+        snprintf(buf, buflen, "hcq_first_kernel<%d, %d, %d, %d, %d>", k.IBC, k.NT1, k.NT2, k.NR, pl.first_rows);
+    else
+        snprintf(buf, buflen, "hcq_conv_kernel<%d, %d, %d, %d, %d, %d, %d>", k.KH, k.KW, k.IBC, k.NT1, k.NT2, k.NR, k.XI);
     return SELD_OK;
 }
 

@@ -389,6 +389,11 @@ def test_hcq_conv_vs_oracle(algebra, shape, cout, k, pad, dil):
     (4, (2, 8, 4, 64), 64),          # quaternion first layer (config 2): 2 block channels
     (8, (1, 48, 3, 64), 128),        # 6 block channels: three chunks of two
     (4, (3, 12, 2, 128), 128),       # 3 block channels: three chunks of one
+    (8, (2, 8, 16, 128), 192),       # image height a multiple of 8: the row-walking kernel (hcq_first_kernel), 3 tiles
+    (8, (1, 16, 8, 192), 192),       # ... two block channels
+    (8, (2, 8, 8, 64), 128),         # ... two tiles
+    (4, (2, 8, 24, 64), 64),         # ... quaternion, one tile
+    (4, (1, 4, 8, 128), 128),        # ... quaternion, one block channel, two tiles
 ])
 def test_hcq_forward_with_padded_k_groups(algebra, shape, cout):
     """3x3 layers whose input has fewer than 4 block channels per K chunk (the networks' first layers): the last k-group
@@ -396,7 +401,7 @@ def test_hcq_forward_with_padded_k_groups(algebra, shape, cout):
     import seld_amd
     H, L = seld_amd.hip_ops, seld_amd._lib
     desc = H.make_conv_desc(tuple(shape), cout, algebra, (3, 3), 1, 1, 1)
-    assert H.hcq_label(desc, 0).startswith("hcq_conv_kernel<3, 3, ")
+    assert H.hcq_label(desc, 0).startswith(("hcq_conv_kernel<3, 3, ", "hcq_first_kernel<"))
     gen = torch.Generator().manual_seed(78)
     x = torch.randn(shape, generator=gen)
     wshape = (cout // algebra, shape[1] // algebra, 3, 3)

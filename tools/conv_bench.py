@@ -47,7 +47,9 @@ def main():
         dy = torch.randn_like(y)
         gw = [torch.zeros_like(w) for w in ws]
         flops, by = H.conv_work(desc, 0)
+        st = H.new_stats(s["cout"], dev)
         fns = {"fwd": lambda: H.conv_fwd(desc, x, ws, out=y),
+               "fwd_stats": lambda: H.conv_fwd(desc, x, ws, out=y, epilogue=seld_amd._lib.SELD_EPI_STATS, stats=st),
                "dgrad": lambda: H.conv_bwd_data(desc, dy, ws, tuple(x.shape)),
                "wgrad": lambda: H.conv_bwd_weight(desc, x, dy, tuple(ws[0].shape), False, into=gw)}
         for which in args.which.split(","):
