@@ -107,8 +107,11 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
 
     // ---- tile position (32-bit arithmetic throughout: the host checked that both tensors are below 4 GB) ------------
     const unsigned tiles_per_row = (unsigned)p.W >> 6;    // 64 consecutive positions inside ONE row (W % 64 == 0)
-    const unsigned row_g = blockIdx.x / tiles_per_row;    // n * Himg + h
-    const int w0 = (int)(blockIdx.x - row_g * tiles_per_row) * 64;
+    // workgroups go round-robin to the 8 XCDs: give each XCD (its own L2) a contiguous range of position tiles, so that
+    // the tiles sharing halo rows / output lines meet in one L2
+    const unsigned bx = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const unsigned row_g = bx / tiles_per_row;            // n * Himg + h
+    const int w0 = (int)(bx - row_g * tiles_per_row) * 64;
     const int n_img = (int)(row_g / (unsigned)p.Himg);
     const int h0 = (int)row_g - n_img * p.Himg;
     const int yt = blockIdx.y;                        // channel tile over all weight sets
