@@ -201,19 +201,25 @@ __global__ __launch_bounds__(SK_NW * 64, (SK_NW == 8 && NG_T) ? 4 : 1) void hc_c
     // experiment switches (wt is unused by the forward): 1 = no stores, 2 = no gathers, 4 = store after the LDS refill;
     // the compile-time-shaped instantiation keeps only bit 4
     const int dbg = NG_T ? (p.wt & 4) : p.wt;
-    long long tile = blockIdx.x;
-    if (tile < ntiles) {
-        if constexpr (SPLIT) gather_split(tile); else gather(tile);
+    // Workgroups go round-robin to the 8 XCDs (one L2 each).  seq -> tile gives every XCD a contiguous range of position
+    // tiles, so that the 64-position pieces of one 2 KB output row are written back by one L2 instead of eight.
+    const bool xcd_ranges = ((ntiles | (long long)gridDim.x) & 7) == 0;
+    auto tile_of = [&](long long s) { return xcd_ranges ? (s & 7) * (ntiles >> 3) + (s >> 3) : s; };
+    long long seq = blockIdx.x;
+    if (seq < ntiles) {
+        if constexpr (SPLIT) gather_split(tile_of(seq)); else gather(tile_of(seq));
         scatter(0);
     }
     __syncthreads();
 
     int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x) {
-        const long long next = tile + gridDim.x;
-        if constexpr (SPLIT) gather_split(next < ntiles ? next : tile);
-        else if (NG_T) gather(next < ntiles ? next : tile);          // unconditional: keeps the loop body one block
-        else if (next < ntiles && !(dbg & 2)) gather(next);
+    for (; seq < ntiles; seq += gridDim.x) {
+        const long long tile = tile_of(seq);
+        const bool has_next = seq + gridDim.x < ntiles;
+        const long long next = has_next ? tile_of(seq + gridDim.x) : tile;
+        if constexpr (SPLIT) gather_split(next);
+        else if (NG_T) gather(next);                                 // unconditional: keeps the loop body one block
+        else if (has_next && !(dbg & 2)) gather(next);
 
         floatx4 acc[CT];                                   // SPLIT: acc[sub * 2 QT + t], t < QT primal, t >= QT dual
 #pragma unroll
@@ -319,12 +325,12 @@ __global__ __launch_bounds__(SK_NW * 64, (SK_NW == 8 && NG_T) ? 4 : 1) void hc_c
         // start only when this tile's stores are acknowledged.  Stores straight from a second, alternating accumulator set
         // with SGPR-base addressing would remove the reuse; not done yet.
         if (DB) {
-            if (next < ntiles) scatter(buf ^ 1);
+            if (has_next) scatter(buf ^ 1);
             lds_barrier();
             buf ^= 1;
         } else {
             lds_barrier();                               // everyone is done reading the image
-            if (next < ntiles) scatter(0);
+            if (has_next) scatter(0);
             lds_barrier();
         }
 
