@@ -121,6 +121,94 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const LinP p, int rows
         }
 }
 
+// The same GEMM with a 48-deep K tile for the classifier heads of the wide models (384 features = 8 blocks of 48):
+// a tile still lies inside one component block, the rows of A are loaded as float4 along K, and both LDS images are read
+// 16 bytes at a time -- 8 barriers instead of 24 for K = 384 and a quarter of the LDS read instructions (the 16-deep
+// kernel above is latency-bound: 45 us for 0.6 GF).  Host: K % 48 == 0 and (real or component block % 48 == 0).
+template <int TRANS>
+__global__ __launch_bounds__(256) void linear_gemm48_kernel(const LinP p, int rows, const float* __restrict__ A,
+                                                            const float* __restrict__ bias, float* __restrict__ out) {
+    constexpr int KS = 48;
+    const int K = TRANS ? p.out_f : p.in_f;
+    const int Nn = TRANS ? p.in_f : p.out_f;
+    __shared__ __attribute__((aligned(16))) float As[64][KS + 4];       // [row][k]
+    __shared__ __attribute__((aligned(16))) float Bs[KS][64 + 4];       // [k][column]
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tr = (tid >> 4) * 4, tn = (tid & 15) * 4;
+    float acc[4][4] = {};
+    const int nn = tid & 63, kq = tid >> 6;
+    const int kblk = (p.kind == SELD_LIN_REAL) ? KS : (TRANS ? p.OA : p.IA);
+    const int nblk = (p.kind == SELD_LIN_REAL) ? Nn : (TRANS ? p.IA : p.OA);
+    const bool nvalid = n0 + nn < Nn;
+    const int nb = nvalid ? (n0 + nn) / nblk : 0;
+    const int nc = nvalid ? (n0 + nn) - nb * nblk : 0;
+    float4 ra[3];
+    float rb[12];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int e = tid + 256 * t;
+            const int r = e / 12, q = e - r * 12;
+            ra[t] = (r0 + r < rows) ? *reinterpret_cast<const float4*>(A + (size_t)(r0 + r) * K + k0 + 4 * q)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int ka = k0 / kblk, kc = k0 - ka * kblk;
+        float sign = 1.f;
+        int comp = 0;
+        if (p.kind == SELD_LIN_QUAT) comp = TRANS ? block_comp(4, ka, nb, &sign) : block_comp(4, nb, ka, &sign);
+        else if (p.kind == SELD_LIN_DUALQ) comp = TRANS ? block_comp(8, nb, ka, &sign) : block_comp(8, ka, nb, &sign);
+        const bool live = nvalid && comp >= 0;
+        const float* wp = live ? (p.kind == SELD_LIN_REAL
+                                      ? p.w.p[0] + (TRANS ? (size_t)(k0 + kq) * p.in_f + (n0 + nn) : (size_t)(n0 + nn) * p.in_f + k0 + kq)
+                                      : p.w.p[comp] + (TRANS ? (size_t)nc * p.OA + kc + kq : (size_t)(kc + kq) * p.OA + nc))
+                               : nullptr;
+        const size_t wstep = (p.kind == SELD_LIN_REAL) ? (TRANS ? (size_t)4 * p.in_f : 4) : (TRANS ? 4 : (size_t)4 * p.OA);
+#pragma unroll
+        for (int t = 0; t < 12; ++t) rb[t] = live ? sign * wp[t * wstep] : 0.f;
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KS) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int e = tid + 256 * t;
+            const int r = e / 12, q = e - r * 12;
+            *reinterpret_cast<float4*>(&As[r][4 * q]) = ra[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 12; ++t) Bs[kq + 4 * t][nn] = rb[t];
+        __syncthreads();
+        if (k0 + KS < K) fetch(k0 + KS);
+#pragma unroll
+        for (int k4 = 0; k4 < KS; k4 += 4) {
+            float4 a4[4], b4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(&As[tr + i][k4]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) b4[kk] = *reinterpret_cast<const float4*>(&Bs[k4 + kk][tn]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc[i][0] += a[kk] * b4[kk].x;
+                    acc[i][1] += a[kk] * b4[kk].y;
+                    acc[i][2] += a[kk] * b4[kk].z;
+                    acc[i][3] += a[kk] * b4[kk].w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + tr + i, n = n0 + tn + j;
+            if (r < rows && n < Nn) out[(size_t)r * Nn + n] = acc[i][j] + (bias ? bias[n] : 0.f);
+        }
+}
+
 // dM[i][o] = sum_r x[r][i] * dy[r][o]
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int rows_per_split, int in_f, int out_f, const float* __restrict__ x,
                                                            const float* __restrict__ dy, float* __restrict__ dM) {
@@ -225,6 +313,14 @@ static int mk_lin(LinP& p, int kind, int in_f, int out_f, const float* const w[8
     return SELD_OK;
 }
 
+// the 48-deep K tile: K a multiple of 48 and every tile inside one component block
+static bool lin_deep_tile(const LinP& p, int trans) {
+    const int K = trans ? p.out_f : p.in_f;
+    if (K % 48) return false;
+    if (p.kind == SELD_LIN_REAL) return true;
+    return (trans ? p.OA : p.IA) % 48 == 0;
+}
+
 }  // namespace seld
 using namespace seld;
 
@@ -235,7 +331,8 @@ extern "C" int seld_hc_linear_fwd(int32_t kind, int32_t rows, int32_t in_feature
     if (rc) return rc;
     if (!x || !w || !y || rows <= 0) return SELD_EINVAL;
     dim3 grid((out_features + 63) / 64, (rows + 63) / 64);
-    hipLaunchKernelGGL((linear_gemm_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, x, bias, y);
+    if (lin_deep_tile(p, 0)) hipLaunchKernelGGL((linear_gemm48_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, x, bias, y);
+    else hipLaunchKernelGGL((linear_gemm_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, x, bias, y);
     return check_launch();
 }
 
@@ -256,7 +353,8 @@ extern "C" int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_feature
     if (dx) {
         if (!w) return SELD_EINVAL;
         dim3 grid((in_features + 63) / 64, (rows + 63) / 64);
-        hipLaunchKernelGGL((linear_gemm_kernel<1>), grid, dim3(256), 0, st, p, rows, dy, (const float*)nullptr, dx);
+        if (lin_deep_tile(p, 1)) hipLaunchKernelGGL((linear_gemm48_kernel<1>), grid, dim3(256), 0, st, p, rows, dy, (const float*)nullptr, dx);
+        else hipLaunchKernelGGL((linear_gemm_kernel<1>), grid, dim3(256), 0, st, p, rows, dy, (const float*)nullptr, dx);
         rc = check_launch();
         if (rc) return rc;
     }

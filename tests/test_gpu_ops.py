@@ -44,6 +44,35 @@ def test_linear_matches_fixture(case, golden):
         _close(bd.grad, g[n + ".dbias"], what="dbias")
 
 
+@pytest.mark.parametrize("kind,fin,fout,rows", [("dq", 384, 384, 130), ("dq", 384, 768, 64), ("q", 192, 192, 70),
+                                                ("q", 384, 126 * 2 + 4, 33)])
+def test_hyper_linear_wide_vs_oracle(kind, fin, fout, rows):
+    """The classifier heads of the wide models: feature counts whose component blocks are multiples of 48 take the
+    48-deep-tile GEMM (csrc/linear.hip) forward and in the data gradient; against the oracle in fp64."""
+    H, L = pkg().hip_ops, pkg()._lib
+    A = 8 if kind == "dq" else 4
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(rows, fin, generator=gen)
+    ws = [torch.randn(fin // A, fout // A, generator=gen) * 0.1 for _ in range(A)]
+    bias = torch.randn(fout, generator=gen)
+    xd = x.to(DEV).requires_grad_(True)
+    wd = [w.to(DEV).requires_grad_(True) for w in ws]
+    bd = bias.to(DEV).requires_grad_(True)
+    y = H.hyper_linear(xd, wd, bd, L.SELD_LIN_DUALQ if kind == "dq" else L.SELD_LIN_QUAT)
+    cot = torch.randn(rows, fout, generator=gen)
+    (y * cot.to(DEV)).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in ws]
+    b64 = bias.double().requires_grad_(True)
+    yr = O.dual_quaternion_linear(x64, w64, b64) if kind == "dq" else O.quaternion_linear(x64, *w64, b64)
+    (yr * cot.double()).sum().backward()
+    _close(y, yr, what="y")
+    _close(xd.grad, x64.grad, what="dx")
+    for i, (a, b) in enumerate(zip(wd, w64)):
+        _close(a.grad, b.grad, rel=5e-4, what=f"dw{i}")
+    _close(bd.grad, b64.grad, what="dbias")
+
+
 def test_real_linear_large():
     hnn = pkg().hip_nn
     torch.manual_seed(0)
