@@ -314,6 +314,15 @@ int seld_hcq_wgrad_label(const seld_conv_desc* desc, int32_t npair, char* buf, i
 int seld_hcq_wgrad_acc(const seld_conv_desc* desc, int32_t npair, const float* x, const float* dyA, const float* dyB,
                        float* const dwA[8], float* const dwB[8], void* stream);
 
+/* The dual-quaternion weight gradient with 24 instead of 48 block products on the row-chunk GEMM (csrc/hcq_wgrad_row.hip;
+ * dual_quaternion_ops.py:122-153 differentiated).  seld_hcq_wgrad_row_workspace: bytes of fp32 scratch for (desc, npair),
+ * 0 = shape not taken.  The scratch must be zero before the first call; every call hands it back zeroed (one buffer per
+ * stream serves all layers).  npair == 2: two convolutions of the same input (dwB[c] += ...), one launch family. */
+size_t seld_hcq_wgrad_row_workspace(const seld_conv_desc* desc, int32_t npair);
+int seld_hcq_wgrad_row_label(const seld_conv_desc* desc, int32_t npair, char* buf, int32_t buflen);
+int seld_hcq_wgrad_row_acc(const seld_conv_desc* desc, int32_t npair, const float* x, const float* dyA, const float* dyB,
+                           float* const dwA[8], float* const dwB[8], void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Elementwise / pooling / dropout   (torch.nn.ReLU/Tanh/MaxPool/Dropout at model.py:175-202,
  * 280-282, 449-451)

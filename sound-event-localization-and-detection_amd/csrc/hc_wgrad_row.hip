@@ -19,6 +19,7 @@
 //
 // Tiling, LDS images ([k-group][row][4 positions], one ds_read_b128 feeds four MFMAs), the dual-quaternion
 // zero-quadrant exit and the atomic fold are those of hc_wgrad32_kernel.
+#include <type_traits>
 #include "hc_common.h"
 
 namespace seld {
@@ -128,14 +129,21 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
     const unsigned nrec_b = (unsigned)(xb > (long long)OOB ? (long long)OOB : xb);
     const int wspan = (KW_T - 1) * p.dw - p.pw;          // last tap's column shift
 
-    floatx4 ar[AR], br[BR];
+    // DEEP (not FUSED): loads run TWO steps ahead of the MFMAs, in two register sets -- a step's 32-128 MFMAs per wave are
+    // shorter than the loaded memory system's latency, so with one step of lead every step ended waiting for its loads
+    constexpr bool DEEP = !FUSED && (AR + BR) <= 7;
+    constexpr int NSET = DEEP ? 2 : 1;
+    floatx4 ars[NSET][AR], brs[NSET][BR];
     floatx4 pz[AR], pd[AR];          // FUSED: pooled activations and their gradient for the step's window row
     unsigned pi[AR];                 // FUSED: four arg-max bytes
     int prow = 0;                    // FUSED: row of the step inside its pooling window
 
     // `advance` is false for the prefetch issued during the last step: it re-reads that step (valid addresses) into
     // the LDS buffer nobody reads, so the loop body needs no branch around its loads and stores.
-    auto load_chunk = [&](bool advance) __attribute__((always_inline)) {
+    auto load_chunk = [&](bool advance, auto setc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
+        floatx4 (&ar)[AR] = ars[SET];
+        floatx4 (&br)[BR] = brs[SET];
         const float* abase = dyz + (long long)t_img * dy_img + (long long)t_oh * p.outW + t_ow;
         const float* bbase = p.x + (long long)t_img * x_img + (long long)(t_oh * p.sh - p.ph) * p.inW + (t_ow - p.pw);
         const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, nrec_a, 0x00020000);
@@ -210,7 +218,10 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
             }
         }
     };
-    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+    auto store_chunk = [&](int buf, auto setc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
+        floatx4 (&ar)[AR] = ars[SET];
+        floatx4 (&br)[BR] = brs[SET];
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             floatx4 a4 = ar[j];
@@ -236,14 +247,9 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
         for (int j = 0; j < CTL; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fk = lane >> 4;
-    if (nchunks > 0) { load_chunk(nchunks > 1); store_chunk(0); }
-    __syncthreads();
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int buf = chunk & 1;
-        if (!(p.dbg & 1)) load_chunk(chunk + 2 < nchunks);
-        // The loads must stay at the top and the LDS stores at the bottom of the step: left alone, the scheduler
-        // hoists the stores (and their vmcnt wait) to the middle, which leaves the loads 48 MFMAs to land.
-        __builtin_amdgcn_sched_barrier(0);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NSET - 1>;
+    auto mfma_step = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             floatx4 av[RT], bv[CTL];
@@ -261,8 +267,38 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
             }
         }
-        if (!(p.dbg & 2)) store_chunk(buf ^ 1);
+    };
+    if constexpr (DEEP) {
+        // step c multiplies LDS[c & 1]; register set (c & 1) holds step c + 1 (stored to LDS after the MFMAs); the loads
+        // issued in step c are those of step c + 2, into the other set
+        if (nchunks > 0) { load_chunk(nchunks > 1, S0{}); store_chunk(0, S0{}); }
+        if (nchunks > 1) load_chunk(nchunks > 2, S0{});
         __syncthreads();
+        auto body = [&](int chunk, auto cur, auto oth) __attribute__((always_inline)) {
+            const int buf = chunk & 1;
+            if (chunk + 2 < nchunks) load_chunk(chunk + 3 < nchunks, oth);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(buf);
+            if (chunk + 1 < nchunks) store_chunk(buf ^ 1, cur);
+            __syncthreads();
+        };
+        for (int chunk = 0; chunk < nchunks; chunk += 2) {
+            body(chunk, S0{}, S1{});
+            if (chunk + 1 < nchunks) body(chunk + 1, S1{}, S0{});
+        }
+    } else {
+        if (nchunks > 0) { load_chunk(nchunks > 1, S0{}); store_chunk(0, S0{}); }
+        __syncthreads();
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int buf = chunk & 1;
+            if (!(p.dbg & 1)) load_chunk(chunk + 2 < nchunks, S0{});
+            // The loads must stay at the top and the LDS stores at the bottom of the step: left alone, the scheduler
+            // hoists the stores (and their vmcnt wait) to the middle, which leaves the loads 48 MFMAs to land.
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(buf);
+            if (!(p.dbg & 2)) store_chunk(buf ^ 1, S0{});
+            __syncthreads();
+        }
     }
 
     // ---- fold the tile into the component gradients ------------------------------------------------------------

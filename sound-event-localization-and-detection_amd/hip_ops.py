@@ -202,7 +202,8 @@ def _hcq_wgrad_ok(desc, npair=1):
     key = (bytes(desc), npair, "wgrad")
     v = _hcq_labels.get(key)
     if v is None:
-        v = _hcq_labels[key] = desc.algebra > 1 and bool(L.lib().seld_hcq_wgrad_supported(ctypes.byref(desc), int(npair)))
+        v = _hcq_labels[key] = desc.algebra > 1 and (_hcq_wgrad_row_bytes(desc, npair) > 0 or
+                                                     bool(L.lib().seld_hcq_wgrad_supported(ctypes.byref(desc), int(npair))))
     return v
 
 
@@ -216,9 +217,51 @@ def _hcq_wgrad_label(desc, npair=1):
     return v
 
 
+def _hcq_wgrad_row_bytes(desc, npair=1):
+    """Scratch bytes of the 24-product dual-quaternion weight gradient (csrc/hcq_wgrad_row.hip), 0 = shape not taken."""
+    key = (bytes(desc), npair, "wgrad_row")
+    v = _hcq_labels.get(key)
+    if v is None:
+        lib = L.lib()
+        lib.seld_hcq_wgrad_row_workspace.restype = ctypes.c_size_t
+        v = _hcq_labels[key] = int(lib.seld_hcq_wgrad_row_workspace(ctypes.byref(desc), int(npair))) if desc.algebra == 8 else 0
+    return v
+
+
+def _hcq_wgrad_row_label(desc, npair=1):
+    key = (bytes(desc), npair, "wgrad_row_label")
+    v = _hcq_labels.get(key)
+    if v is None:
+        buf = ctypes.create_string_buffer(96)
+        L.check(L.lib().seld_hcq_wgrad_row_label(ctypes.byref(desc), int(npair), buf, 96), "seld_hcq_wgrad_row_label")
+        v = _hcq_labels[key] = buf.value.decode()
+    return v
+
+
+_wgrad_row_scratch = {}      # (device, stream) -> zeroed fp32 scratch; every call hands it back zeroed
+
+
+def _wgrad_row_ws(nbytes, device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _wgrad_row_scratch.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = _wgrad_row_scratch[key] = torch.zeros((nbytes + 3) // 4, device=device, dtype=torch.float32)
+    return t
+
+
 def hcq_wgrad_acc(desc, x, dyA, dwA, dyB=None, dwB=None):
-    """dwA[c] += wgrad(x, dyA) [, dwB[c] += wgrad(x, dyB)] on the fast-product kernel (seld_hcq_wgrad_acc)."""
+    """dwA[c] += wgrad(x, dyA) [, dwB[c] += wgrad(x, dyB)] on the fast-product kernels: the row-chunk GEMM on forms for
+    the dual quaternion (seld_hcq_wgrad_row_acc), else seld_hcq_wgrad_acc."""
     npair = 2 if dyB is not None else 1
+    nbytes = _hcq_wgrad_row_bytes(desc, npair)
+    if nbytes:
+        ws = _wgrad_row_ws(nbytes, x.device)
+        with _Timed(desc, 2, npair, label=_hcq_wgrad_row_label(desc, npair) if kernel_timer.active else None):
+            L.check(L.lib().seld_hcq_wgrad_row_acc(ctypes.byref(desc), npair, L.ptr(x), L.ptr(dyA), L.ptr(dyB),
+                                                   L.ptr_array8(dwA), L.ptr_array8(dwB) if dwB is not None else None,
+                                                   L.ptr(ws), ctypes.c_size_t(ws.numel() * 4), L.current_stream()),
+                    "seld_hcq_wgrad_row_acc")
+        return
     with _Timed(desc, 2, npair, label=_hcq_wgrad_label(desc, npair) if kernel_timer.active else None):
         L.check(L.lib().seld_hcq_wgrad_acc(ctypes.byref(desc), npair, L.ptr(x), L.ptr(dyA), L.ptr(dyB), L.ptr_array8(dwA),
                                            L.ptr_array8(dwB) if dwB is not None else None, L.current_stream()),

@@ -499,3 +499,51 @@ def test_hcq_wgrad_matches_block_matrix_kernels(algebra, shape, cout, k, pad, di
         if H._hcq_wgrad_ok(desc, 2):
             for a, b in zip(new[1] + new[2], old[0] + old[1]):
                 _close(a, b)
+
+
+@pytest.mark.parametrize("shape,cout,k,pad,dil", [
+    ((8, 192, 512), 384, 3, 5, 5),               # TCN filter / gate: 48 output block channels, 72 columns (one group of 96)
+    ((8, 384, 512), 192, 1, 0, 1),               # skip / residual: 24 block channels, 48 columns (one group of 64)
+    ((2, 192, 8, 512), 192, (3, 3), 1, 1),       # cnn.1 / cnn.2: 216 columns = four groups of 64
+    ((1, 192, 8, 512), 384, (3, 3), 1, 1),       # 48 block channels x 216 columns
+    ((9, 192, 512), 384, 3, 55, 55),             # dilation wider than a step: every step gathers at the row ends; odd split
+])
+def test_hcq_wgrad_row_matches_block_matrix_kernels(shape, cout, k, pad, dil, seld_env):
+    """The 24-product dual-quaternion weight gradient (hcq_wgrad_row.hip: forms staged into the row-chunk GEMM, two tile
+    families + fold, single and pair launches, scratch handed back zeroed) against the 48-product kernels, which the
+    oracle tests pin; the first shape also against the oracle directly."""
+    import seld_amd
+    H = seld_amd.hip_ops
+    seld_env.set("SELD_HCQ_WGRAD_ROW", "1")              # opt-in: correct, not yet faster than the 48-product kernels
+    kk = (k,) if isinstance(k, int) else k
+    desc = H.make_conv_desc(tuple(shape), cout, 8, kk, 1, pad, dil)
+    assert H._hcq_wgrad_row_bytes(desc) > 0 and H._hcq_wgrad_row_bytes(desc, 2) > 0
+    assert H._hcq_wgrad_row_label(desc).startswith("hcq_wgrad_row_kernel<")
+    gen = torch.Generator().manual_seed(13)
+    dev = torch.device("cuda:0")
+    x = torch.randn(shape, generator=gen).to(dev)
+    wshape = (cout // 8, shape[1] // 8) + tuple(kk)
+    yshape = (shape[0], cout) + tuple(shape[2:])
+    dyA, dyB = torch.randn(yshape, generator=gen).to(dev), torch.randn(yshape, generator=gen).to(dev)
+    new = [[torch.zeros(wshape, device=dev) for _ in range(8)] for _ in range(3)]
+    H.hcq_wgrad_acc(desc, x, dyA, new[0])
+    H.hcq_wgrad_acc(desc, x, dyA, new[1], dyB, new[2])
+    H.hcq_wgrad_acc(desc, x, dyA, new[0])                       # accumulates; the scratch came back zeroed
+    for ws in H._wgrad_row_scratch.values():
+        assert float(ws.abs().max()) == 0.0
+    seld_env.set("SELD_CONV_NO_HCQ", "1")
+    assert H._hcq_wgrad_row_bytes(desc) == 0
+    old = [[torch.zeros(wshape, device=dev) for _ in range(8)] for _ in range(2)]
+    H.conv_bwd_weight(desc, x, dyA, wshape, False, into=old[0])
+    H.conv_bwd_weight(desc, x, dyB, wshape, False, into=old[1])
+    for a, b in zip(new[0], old[0]):
+        _close(a, 2.0 * b)
+    for a, b in zip(new[1] + new[2], old[0] + old[1]):
+        _close(a, b)
+    if shape == (8, 192, 512):
+        x64 = x.cpu().double()
+        w64 = [torch.zeros(wshape, dtype=torch.float64, requires_grad=True) for _ in range(8)]
+        yr = O.hypercomplex_conv(x64, w64, None, 1, pad, 1, dil, mode="explicit")
+        (yr * dyB.cpu().double()).sum().backward()
+        for a, b in zip(new[2], w64):
+            _close(a, b.grad)
