@@ -232,6 +232,13 @@ def main():
             step_mode = f"eager (graph recording failed: {type(exc).__name__}: {str(exc)[:120]})"
             if rank == 0:
                 print("bench: " + step_mode, file=sys.stderr)
+    if world > 1:
+        # a recording that failed on ONE rank must not leave the ranks on different step sequences (their collectives
+        # would no longer pair up): everybody falls back together
+        ok = torch.tensor([1.0 if step is not eager_step or args.mode == "eager" else 0.0], device=dev)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if ok.item() < 0.5 and step is not eager_step:
+            step, step_mode = eager_step, "eager (graph recording failed on another rank)"
     if args.mode == "auto" and step is not eager_step:
         # both issue the same kernels; which one is faster depends on how fast this host launches (eager) against
         # what the graph replay costs: 6 untimed steps each, rank 0 decides for everybody
