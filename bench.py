@@ -83,9 +83,14 @@ def pmc_traffic(kernel_label):
     if not files:
         return None, None
     try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel_label)
+        kernels = json.load(open(files[-1]))["kernels"]
     except (OSError, ValueError, KeyError):
         return None, None
+    k = kernels.get(kernel_label)
+    if k is None:          # the timer's label may carry fewer template arguments than the profiler's symbol
+        stem = kernel_label.rstrip(">")
+        hits = [v for name, v in kernels.items() if name.startswith(stem + ",") or name.startswith(stem + ">")]
+        k = hits[0] if len(hits) == 1 else None
     return (round(k["traffic_bytes"]) if k else None), os.path.relpath(files[-1], ROOT)
 
 
@@ -323,7 +328,8 @@ def main():
                 else:
                     roof = dict(bound="mfma", achieved=r["tflops"], peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                                 frac=round(r["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4))
-                traffic, src = pmc_traffic(label)
+                # the committed counter passes are of the default workload (c3, batch 32, F = 128)
+                traffic, src = pmc_traffic(label) if (args.workload == "c3" and batch == 32 and args.freq == 128) else (None, None)
                 if label.startswith("hcq_"):
                     # the fast-product kernels EXECUTE half of the algorithmic flops the roofline is quoted in
                     # (8 real sub-products per Hamilton product instead of 16; 24 instead of 48 for the dual
