@@ -578,6 +578,38 @@ class _HcqWeights:
 hcq_weights = _HcqWeights()
 
 
+# ---- the two branches of the two-stream model on two queues --------------------------------------------------------
+_branch = {"stream": None}
+
+
+def two_queue_branches():
+    """SELD_BRANCH_STREAMS=0 turns the second queue off (both branches then run one after the other on the caller's)."""
+    return os.environ.get("SELD_BRANCH_STREAMS", "1") != "0"
+
+
+def run_branches(fa, xa, fb, xb):
+    """(fa(xa), fb(xb)) with fb on a second HIP stream: the two ConvTC blocks of the two-stream model (model.py:463-471)
+    are independent until their outputs are concatenated, and at 16 samples per GPU neither fills the device by itself.
+    Autograd replays each branch's backward on the stream its forward ran on and orders the streams at the fork and
+    the join; the weight forms are packed BEFORE the fork (they are packed once per step, by whoever asks first)."""
+    if not (xa.is_cuda and two_queue_branches()):
+        return fa(xa), fb(xb)
+    if hcq_weights.packed_epoch != hcq_weights.epoch:
+        hcq_weights._pack_all()
+    main = torch.cuda.current_stream()
+    if _branch["stream"] is None:
+        _branch["stream"] = torch.cuda.Stream()
+    sb = _branch["stream"]
+    sb.wait_stream(main)
+    xb.record_stream(sb)
+    ya = fa(xa)                      # host order A, B as on one queue: the dropout counters are drawn in the same order
+    with torch.cuda.stream(sb):
+        yb = fb(xb)
+    main.wait_stream(sb)
+    yb.record_stream(main)
+    return ya, yb
+
+
 def _drop_kernel_choice_caches():
     hcq_weights.reset()
     _hcq_labels.clear()
@@ -827,14 +859,14 @@ def _ncs(x):
 STATS_REPLICAS = 64      # SELD_STATS_REPLICAS
 
 
-_stats_pool = {}     # (C, device) -> zero-filled statistics buffers ready for reuse
+_stats_pool = {}     # (C, device, stream) -> zero-filled statistics buffers ready for reuse
 
 
 def new_stats(C, device):
     """Zeroed BatchNorm statistics buffer: SELD_STATS_REPLICAS rows of [sum(C) | sum of squares(C)].  Buffers are
     pooled: `bn_prepare` hands one back after `seld_bn_finalize_ex` has consumed AND re-zeroed it, so a training step
     does not launch a fill per BatchNorm."""
-    free = _stats_pool.get((C, device))
+    free = _stats_pool.get((C, device, torch.cuda.current_stream(device).cuda_stream))
     if free:
         return free.pop()
     t = torch.zeros(STATS_REPLICAS * 2 * C, device=device, dtype=torch.float32)
@@ -863,8 +895,8 @@ def bn_prepare(x, running_mean, running_var, training, momentum, eps, stats=None
                                             ctypes.c_float(momentum), L.ptr(mean), L.ptr(invstd), L.ptr(running_mean),
                                             L.ptr(running_var), L.ptr(num_batches_tracked), int(pooled),
                                             L.current_stream()), "seld_bn_finalize_ex")
-        if pooled:
-            _stats_pool.setdefault((C, x.device), []).append(stats)
+        if pooled:      # per stream: the buffer is re-zeroed by a kernel on THIS stream and may only be reused in order behind it
+            _stats_pool.setdefault((C, x.device, torch.cuda.current_stream(x.device).cuda_stream), []).append(stats)
     else:
         L.check(L.lib().seld_bn_eval_stats(L.ptr(running_mean), L.ptr(running_var), C, ctypes.c_float(eps),
                                            L.ptr(mean), L.ptr(invstd), L.current_stream()), "seld_bn_eval_stats")

@@ -399,7 +399,8 @@ class SELD_Model(nn.Module):
             else:
                 h = self.input_channels // 2
                 x_A, x_B = x[:, :h].contiguous(), x[:, h:].contiguous()
-            x = torch.cat((self.branch_A(x_A), self.branch_B(x_B)), 2)
+            y_A, y_B = H.run_branches(self.branch_A, x_A, self.branch_B, x_B)
+            x = torch.cat((y_A, y_B), 2)
         else:
             x = self.seld_block(x)
         return self.sed(x), self.doa(x)

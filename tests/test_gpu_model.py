@@ -292,3 +292,45 @@ def test_side_stream_lag_does_not_corrupt_gradients(monkeypatch):
     assert scale > 0
     err = float((got - ref).abs().max())
     assert err <= 1e-4 * scale, f"side-stream lag changed the gradients: {err:.3e} of {scale:.3e}"
+
+
+def test_two_stream_branches_on_two_queues_match_one_queue(monkeypatch):
+    """The two ConvTC blocks of the two-stream model run on two HIP streams (hip_ops.run_branches).  Make the second queue
+    lag far behind the first (a long sleep queued on it before the step) and require the same outputs, loss and
+    gradients as with both branches on one queue, for two consecutive steps (the second reuses pooled statistics
+    buffers and the packed weight forms across the streams)."""
+    H, T = pkg().hip_ops, pkg().train
+    case = next(c for c in MODEL_CASES if c["name"] == "tiny_2stream")
+    x = O.closed_form_input((case["B"], case["input_channels"], case["freq_dim"], case["time_dim"])).to(DEV)
+    target = train_target(case).to(DEV)
+    n_sed = int(case["output_classes"] * 3)
+
+    def run(two_queues):
+        monkeypatch.setenv("SELD_BRANCH_STREAMS", "1" if two_queues else "0")
+        torch.manual_seed(3)
+        H.philox.set_offset(0)
+        m = _prepared(case).train()
+        opt = T.FlatAdam(m.parameters(), lr=1e-3)
+        out = []
+        for step in range(2):
+            opt.zero_grad()
+            if two_queues and step == 0:
+                if H._branch["stream"] is None:
+                    H._branch["stream"] = torch.cuda.Stream()
+                with torch.cuda.stream(H._branch["stream"]):
+                    torch.cuda._sleep(200_000_000)       # ~0.1 s: whatever the main queue does not wait for, it now overtakes
+            sed, doa = m(x)
+            loss = T.seld_loss_fn(sed, doa, target, n_sed, 1.0, 5.0)
+            loss.backward()
+            H.join_side_stream()
+            torch.cuda.synchronize()
+            out.append((sed.detach().clone(), doa.detach().clone(), float(loss.detach()), opt.flat_grad.detach().clone()))
+            opt.step()
+        return out
+
+    ref, got = run(False), run(True)
+    for (s0, d0, l0, g0), (s1, d1, l1, g1) in zip(ref, got):
+        assert float((s0 - s1).abs().max()) <= 1e-5 and float((d0 - d1).abs().max()) <= 1e-5
+        assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0))
+        scale = float(g0.abs().max())
+        assert float((g0 - g1).abs().max()) <= 2e-4 * scale
