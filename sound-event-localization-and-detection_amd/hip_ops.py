@@ -588,8 +588,9 @@ def two_queue_branches():
 
 
 def run_branches(fa, xa, fb, xb):
-    """(fa(xa), fb(xb)) with fb on a second HIP stream: the two ConvTC blocks of the two-stream model (model.py:463-471)
-    are independent until their outputs are concatenated, and at 16 samples per GPU neither fills the device by itself.
+    """(fa(xa), fb(xb)) with fb on a second HIP stream.  Used for the two ConvTC blocks of the two-stream model
+    (model.py:463-471: independent until their outputs are concatenated, and at 16 samples per GPU neither fills the
+    device by itself) and for the SED / DOA classifier heads (model.py:473-480: two chains of small-grid kernels).
     Autograd replays each branch's backward on the stream its forward ran on and orders the streams at the fork and
     the join; the weight forms are packed BEFORE the fork (they are packed once per step, by whoever asks first)."""
     if not (xa.is_cuda and two_queue_branches()):

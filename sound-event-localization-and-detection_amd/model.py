@@ -403,7 +403,8 @@ class SELD_Model(nn.Module):
             x = torch.cat((y_A, y_B), 2)
         else:
             x = self.seld_block(x)
-        return self.sed(x), self.doa(x)
+        # the two classifier heads are independent chains of small-grid kernels: two queues (hip_ops.run_branches)
+        return H.run_branches(self.sed, x, self.doa, x)
 
     def calculate_receptive_field(self, verbose=0):
         """model.py:482-517."""

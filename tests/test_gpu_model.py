@@ -294,13 +294,15 @@ def test_side_stream_lag_does_not_corrupt_gradients(monkeypatch):
     assert err <= 1e-4 * scale, f"side-stream lag changed the gradients: {err:.3e} of {scale:.3e}"
 
 
-def test_two_stream_branches_on_two_queues_match_one_queue(monkeypatch):
-    """The two ConvTC blocks of the two-stream model run on two HIP streams (hip_ops.run_branches).  Make the second queue
+@pytest.mark.parametrize("name", ["tiny_2stream", "tiny_DQ"])
+def test_two_stream_branches_on_two_queues_match_one_queue(name, monkeypatch):
+    """The two ConvTC blocks of the two-stream model, and the two classifier heads of every model, run on two HIP streams
+    (hip_ops.run_branches).  Make the second queue
     lag far behind the first (a long sleep queued on it before the step) and require the same outputs, loss and
     gradients as with both branches on one queue, for two consecutive steps (the second reuses pooled statistics
     buffers and the packed weight forms across the streams)."""
     H, T = pkg().hip_ops, pkg().train
-    case = next(c for c in MODEL_CASES if c["name"] == "tiny_2stream")
+    case = next(c for c in MODEL_CASES if c["name"] == name)
     x = O.closed_form_input((case["B"], case["input_channels"], case["freq_dim"], case["time_dim"])).to(DEV)
     target = train_target(case).to(DEV)
     n_sed = int(case["output_classes"] * 3)
