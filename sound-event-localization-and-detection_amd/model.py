@@ -136,7 +136,7 @@ class ResBlock(nn.Module):
         return H.hyper_conv_pair(x, _components(conv_a), conv_a.bias, _components(conv_b), conv_b.bias, s, p, d,
                                  add_a, add_b, stats_a, stats_b)
 
-    def fused(self, x, skip_sum=None, need_residual=True, x_stats=None, want_res_stats=False):
+    def fused(self, x, skip_sum=None, need_residual=True, x_stats=None, want_res_stats=False, mask=None):
         """Returns (x_hat + conv2_residual(y)  or None, skip_sum + conv2_skip(y), statistics of the residual or None).
         The BatchNorm batch statistics of a convolution's result are gathered by that convolution's epilogue:
         x_stats are those of this block's input (from the previous block), the returned ones go to the next block."""
@@ -150,8 +150,7 @@ class ResBlock(nn.Module):
         st_f = H.new_stats(self.batch_filter2.num_features, x.device) if train_stats else None
         st_g = H.new_stats(self.batch_gate2.num_features, x.device) if train_stats else None
         yf, yg = self._conv_pair(self.conv1_filter, self.conv1_gate, x, None, None, st_f, st_g)
-        mask = None
-        if self.training and not self.spatial_dropout_rate == 0:
+        if mask is None and self.training and not self.spatial_dropout_rate == 0:
             mask = H.channel_dropout_mask(yf.shape[0], yf.shape[1], self.spatial_dropout_rate, yf.device)
         if bn:
             y = H.gate(yf, yg, self.batch_filter2, self.batch_gate2, mask, st_f, st_g)
@@ -180,6 +179,7 @@ class TC_Block(nn.Module):
                  verbose=False, attention_type=None, key_size=None, value_size=None):
         super().__init__()
         self.verbose, self.D, self.pool_time, self.domain = verbose, D, pool_time, domain
+        self._gate_channels = G
         self.ResBlocks = nn.ModuleList()
         for d in self.dilation_schedule(D, dilation_mode):
             self.ResBlocks.append(ResBlock(in_channels=in_channels, domain=domain, G=G, U=U,
@@ -218,13 +218,30 @@ class TC_Block(nn.Module):
                 out.append(dil)
         return out
 
+    def _dropout_masks(self, x):
+        """The Dropout1d channel masks of ALL residual blocks from one launch.  Nothing else draws random numbers between
+        the blocks, so block i's rows are exactly what its own launch would have produced (consecutive Philox groups,
+        rows % 4 == 0); otherwise every block draws for itself."""
+        blocks = list(self.ResBlocks)
+        if not (self.training and x.is_cuda and blocks):
+            return None
+        rate = blocks[0].spatial_dropout_rate
+        G = self._gate_channels
+        if rate == 0 or any(b.spatial_dropout_rate != rate for b in blocks):
+            return None
+        rows = x.shape[0] * G
+        if rows % 4:
+            return None
+        return H.channel_dropout_mask(x.shape[0] * len(blocks), G, rate, x.device).view(len(blocks), rows)
+
     def forward(self, residual):
         skip = None
         last = len(self.ResBlocks) - 1
         stats = None                     # batch statistics of `residual`, gathered by the convolution that wrote it
+        masks = self._dropout_masks(residual)
         for i, blk in enumerate(self.ResBlocks):
             residual, skip, stats = blk.fused(residual, skip, need_residual=i < last, x_stats=stats,
-                                              want_res_stats=i < last)
+                                              want_res_stats=i < last, mask=None if masks is None else masks[i])
         out = self.relu1(skip)
         if self.pool_time == 'TCN':
             out = self.maxpool1(out)
