@@ -195,6 +195,13 @@ int seld_bn_finalize_ex(float* stats, int32_t C, int64_t count, float eps, float
                         float* running_var /* nullable */, int64_t* num_batches_tracked /* nullable */,
                         int32_t clear_stats, void* stream);
 
+/* two BatchNorm layers of the same channel count in one launch (batch_filter2 / batch_gate2 of a residual block,
+ * model.py:123-126, whose statistics the one filter|gate pair convolution gathered) */
+int seld_bn_finalize2_ex(float* statsA, float* statsB, int32_t C, int64_t count, float eps, float momentum,
+                         float* meanA, float* invstdA, float* running_meanA, float* running_varA,
+                         int64_t* num_batches_trackedA, float* meanB, float* invstdB, float* running_meanB,
+                         float* running_varB, int64_t* num_batches_trackedB, int32_t clear_stats, void* stream);
+
 /* eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps) */
 int seld_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
                        float* mean, float* invstd, void* stream);

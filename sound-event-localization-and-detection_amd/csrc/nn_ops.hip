@@ -119,6 +119,39 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ st
     }
 }
 
+// Two BatchNorms of the same channel count in one launch (the gate's batch_filter2 / batch_gate2, whose statistics come
+// from one pair convolution): blockIdx.y selects the layer.
+struct BnFin {
+    float* stats; float* mean; float* invstd; float* rmean; float* rvar; long long* nbt;
+};
+__global__ __launch_bounds__(256) void bn_finalize2_kernel(BnFin a, BnFin b, int C, double count, float eps, float momentum, int clear) {
+    const BnFin& f = blockIdx.y ? b : a;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && f.nbt) *f.nbt += 1;
+    if (c >= C) return;
+    float* p1 = f.stats + (size_t)lane * 2 * C + c;
+    float* p2 = p1 + C;
+    double s1 = (double)*p1, s2 = (double)*p2;
+    if (clear) { *p1 = 0.f; *p2 = 0.f; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (lane != 0) return;
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    f.mean[c] = (float)m;
+    f.invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (f.rmean) f.rmean[c] = (1.f - momentum) * f.rmean[c] + momentum * (float)m;
+    if (f.rvar) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        f.rvar[c] = (1.f - momentum) * f.rvar[c] + momentum * (float)unbiased;
+    }
+}
+
 // eval mode: mean = running_mean, invstd = rsqrt(running_var + eps)
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C, float eps,
                                      float* __restrict__ mean, float* __restrict__ invstd) {
@@ -821,6 +854,18 @@ extern "C" int seld_bn_finalize_ex(float* stats, int32_t C, int64_t count, float
     if (!stats || !mean || !invstd || C <= 0 || count <= 0) return SELD_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, ST(stream), stats, C, (double)count, eps,
                        momentum, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, clear_stats);
+    return check_launch();
+}
+
+extern "C" int seld_bn_finalize2_ex(float* statsA, float* statsB, int32_t C, int64_t count, float eps, float momentum,
+                                    float* meanA, float* invstdA, float* running_meanA, float* running_varA,
+                                    int64_t* nbtA, float* meanB, float* invstdB, float* running_meanB,
+                                    float* running_varB, int64_t* nbtB, int32_t clear_stats, void* stream) {
+    if (!statsA || !statsB || !meanA || !invstdA || !meanB || !invstdB || C <= 0 || count <= 0) return SELD_EINVAL;
+    const BnFin a{statsA, meanA, invstdA, running_meanA, running_varA, (long long*)nbtA};
+    const BnFin b{statsB, meanB, invstdB, running_meanB, running_varB, (long long*)nbtB};
+    hipLaunchKernelGGL(bn_finalize2_kernel, dim3((C + 3) / 4, 2), dim3(256), 0, ST(stream), a, b, C, (double)count, eps,
+                       momentum, clear_stats);
     return check_launch();
 }
 

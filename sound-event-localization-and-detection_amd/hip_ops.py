@@ -1022,8 +1022,19 @@ class GateFn(torch.autograd.Function):
                 stats_f=None, stats_g=None):
         yf, yg = _req(yf, "yf"), _req(yg, "yg")
         N, C, S = _ncs(yf)
-        mf, isf = bn_prepare(yf, rmf, rvf, training, momentum, eps, stats_f, nbt_f)
-        mg, isg = bn_prepare(yg, rmg, rvg, training, momentum, eps, stats_g, nbt_g)
+        if (training and stats_f is not None and stats_g is not None and getattr(stats_f, "_seld_pooled", False)
+                and getattr(stats_g, "_seld_pooled", False)):
+            # both layers' statistics are ready (the pair convolution gathered them): one finalize launch for the two
+            mf, isf, mg, isg = (torch.empty(C, device=yf.device, dtype=torch.float32) for _ in range(4))
+            L.check(L.lib().seld_bn_finalize2_ex(L.ptr(stats_f), L.ptr(stats_g), C, ctypes.c_int64(N * S), ctypes.c_float(eps),
+                                                 ctypes.c_float(momentum), L.ptr(mf), L.ptr(isf), L.ptr(rmf), L.ptr(rvf),
+                                                 L.ptr(nbt_f), L.ptr(mg), L.ptr(isg), L.ptr(rmg), L.ptr(rvg), L.ptr(nbt_g),
+                                                 1, L.current_stream()), "seld_bn_finalize2_ex")
+            key = (C, yf.device, torch.cuda.current_stream(yf.device).cuda_stream)
+            _stats_pool.setdefault(key, []).extend((stats_f, stats_g))
+        else:
+            mf, isf = bn_prepare(yf, rmf, rvf, training, momentum, eps, stats_f, nbt_f)
+            mg, isg = bn_prepare(yg, rmg, rvg, training, momentum, eps, stats_g, nbt_g)
         y = torch.empty_like(yf)
         L.check(L.lib().seld_gate_fwd(L.ptr(yf), L.ptr(yg), N, C, S, L.ptr(mf), L.ptr(isf), L.ptr(gf), L.ptr(bf),
                                       L.ptr(mg), L.ptr(isg), L.ptr(gg), L.ptr(bg), L.ptr(mask), L.ptr(y),
