@@ -110,7 +110,10 @@ def test_two_rank_graphed_step_matches_eager(tmp_path):
     # move by up to lr per step in either run (tests/test_gpu_model.py::test_six_step_trajectory has the calibration);
     # the mean deviation is what shows a wrong exchange
     d = (g0["param"] - e0["param"]).abs()
-    assert d.mean().item() <= 0.02 * 1e-3 and d.max().item() <= 4.5e-3, (d.mean().item(), d.max().item())
+    lr, steps = 1e-3, 4
+    assert d.mean().item() <= 0.02 * lr, d.mean().item()
+    assert (d > 0.1 * lr).float().mean().item() <= 2e-3, (d > 0.1 * lr).float().mean().item()
+    assert d.max().item() <= 2 * steps * lr * 1.01, d.max().item()       # the hard bound: lr per step, either way
 
 
 def _one_process_steps(mode, steps, dropout):
@@ -153,8 +156,14 @@ def test_graphed_step_matches_eager_step():
     # the first steps agree to rounding; later ones can part by ~1e-3 when a float-atomic ordering difference flips
     # a pooling arg-max (two eager runs do the same: tools/diag_r2.py)
     assert np.allclose(lg[:3], le[1:4], rtol=2e-4) and np.allclose(lg, le[1:], rtol=3e-3), (lg, le)
+    # Parameters: Adam moves a parameter by up to lr per step whatever the size of its gradient, so one whose gradient is
+    # float-atomic noise around zero can end anywhere within 2 * steps * lr of its twin (observed maxima 3e-3..6e-3 from
+    # run to run).  Bound the bulk tightly and the stragglers by that hard limit.
     d = (pg - pe).abs()
-    assert d.mean().item() <= 0.02 * 1e-3 and d.max().item() <= 5.5e-3, (d.mean().item(), d.max().item())
+    lr, steps = 1e-3, 5
+    assert d.mean().item() <= 0.02 * lr, d.mean().item()
+    assert (d > 0.1 * lr).float().mean().item() <= 2e-3, (d > 0.1 * lr).float().mean().item()
+    assert d.max().item() <= 2 * steps * lr * 1.01, d.max().item()
     assert opt.step_count == 5
     for k in sde:
         if k.endswith("num_batches_tracked"):
