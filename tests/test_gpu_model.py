@@ -331,8 +331,11 @@ def test_two_stream_branches_on_two_queues_match_one_queue(name, monkeypatch):
         return out
 
     ref, got = run(False), run(True)
-    for (s0, d0, l0, g0), (s1, d1, l1, g1) in zip(ref, got):
-        assert float((s0 - s1).abs().max()) <= 1e-5 and float((d0 - d1).abs().max()) <= 1e-5
-        assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0))
+    # step 0 agrees to float-atomic ordering noise; step 1 starts from parameters that Adam moved by up to lr wherever a
+    # gradient is such noise (see tests/test_gpu_dp.py), so it is held to what a missed dependency would break, not more
+    for step, ((s0, d0, l0, g0), (s1, d1, l1, g1)) in enumerate(zip(ref, got)):
+        tol = 1e-5 if step == 0 else 2e-3
+        assert float((s0 - s1).abs().max()) <= tol and float((d0 - d1).abs().max()) <= tol, step
+        assert abs(l0 - l1) <= tol * max(1.0, abs(l0)), step
         scale = float(g0.abs().max())
-        assert float((g0 - g1).abs().max()) <= 2e-4 * scale
+        assert float((g0 - g1).abs().max()) <= (2e-4 if step == 0 else 5e-2) * scale, step
