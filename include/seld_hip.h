@@ -273,6 +273,20 @@ int seld_gate_bwd_apply(const float* dy, const float* yf, const float* yg, int32
                         const float* mean_g, const float* invstd_g, const float* gamma_g, const float* beta_g,
                         const float* mask, const float* red, int32_t train, float* dyf, float* dyg, void* stream);
 
+/* First stage with the pooling decision inside the convolution (csrc/hcq_conv.hip hcq_first_pool_kernel): for
+ * conv -> BatchNorm2d -> ReLU -> MaxPool2d(8, 1) on the network input (model.py:273-281) the sign of gamma says whether a
+ * window's maximum after BatchNorm + ReLU sits at the largest or the smallest conv output, so the convolution writes y,
+ * the batch statistics and, per window, that raw value and its row; seld_bn_pool_finish applies relu(a v + b) on the
+ * pooled-size tensor once the statistics are final.  wpack = seld_hcq_pack(desc, mode 2, ...); SELD_EUNSUPPORTED unless
+ * seld_hcq_pack_floats(desc, 2, 1) > 0 (3x3 'same', 1-2 input block channels, height % 8 == 0, width % 64 == 0). */
+int seld_hcq_first_pool(const seld_conv_desc* desc, const float* x, const float* wpack, const float* bias,
+                        const float* gamma, int32_t want_stats, float* y, float* stats, float* pool_raw, uint8_t* idx,
+                        void* stream);
+/* out (nullable) = Dropout(p)(pooled) in the same pass, the mask seld_dropout_fwd would draw for (seed, offset, state) */
+int seld_bn_pool_finish(const float* raw, int32_t N, int32_t C, int32_t S /* pooled H * W */, const float* mean,
+                        const float* invstd, const float* gamma, const float* beta, float* pooled, float p, uint64_t seed,
+                        uint64_t offset, const uint64_t* state, float* out, void* stream);
+
 /* One-pass training-mode backward of the gate (adds into red[4C]; SELD_EUNSUPPORTED when S % 4 != 0 or N*S > 16384). */
 int seld_gate_bwd_fused(const float* dy, const float* yf, const float* yg, int32_t N, int32_t C, int32_t S,
                         const float* mean_f, const float* invstd_f, const float* gamma_f, const float* beta_f,

@@ -35,6 +35,7 @@ static void load_env_locked() {
     e.conv_no_hcq = flag("SELD_CONV_NO_HCQ");
     e.hcq_wgrad_dq = flag("SELD_HCQ_WGRAD_DQ");
     e.hcq_no_first = flag("SELD_HCQ_NO_FIRST");
+    e.hcq_no_pool = flag("SELD_HCQ_NO_POOL");
     e.hcq_wgrad_row = flag("SELD_HCQ_WGRAD_ROW");
     e.wgrad_norow = flag("SELD_WGRAD_NOROW");
     e.wgrad_slow = flag("SELD_WGRAD_SLOW");

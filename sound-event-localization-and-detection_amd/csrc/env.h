@@ -4,7 +4,7 @@
 // Selection switches -- every setting computes the same results, they only choose which kernel generation runs
 // (the test suite uses them to cover every generation):
 //   SELD_CONV_CFG=ct,pt   force the convolution tile (one of the candidates of pick_cfg, anything else is ignored)
-//   SELD_CONV_NOVEC / SELD_CONV_NOFAST / SELD_CONV_NO_SMALLK / SELD_NO_FWD_PAIR / SELD_CONV_PAIR / SELD_CONV_NO_HCQ / SELD_HCQ_NO_FIRST / SELD_HCQ_WGRAD_DQ / SELD_HCQ_WGRAD_ROW
+//   SELD_CONV_NOVEC / SELD_CONV_NOFAST / SELD_CONV_NO_SMALLK / SELD_NO_FWD_PAIR / SELD_CONV_PAIR / SELD_CONV_NO_HCQ / SELD_HCQ_NO_FIRST / SELD_HCQ_NO_POOL / SELD_HCQ_WGRAD_DQ / SELD_HCQ_WGRAD_ROW
 //   SELD_WGRAD_NOROW / SELD_WGRAD_SLOW / SELD_WGRAD_CFG=0..5 / SELD_WGRAD_WGS=n / SELD_SMALLK_WGS=n
 //   SELD_MHA_NO_MFMA
 // Timing-experiment switches that switch parts of a kernel OFF and therefore give WRONG results exist only in
@@ -20,6 +20,7 @@ struct SeldEnv {
     bool hcq_wgrad_dq = false;                      // SELD_HCQ_WGRAD_DQ: fast-product weight gradient for the dual quaternion too
     bool conv_no_hcq = false;                       // SELD_CONV_NO_HCQ: 16/48-product kernels instead of hcq_conv.hip
     bool hcq_wgrad_row = false;                     // SELD_HCQ_WGRAD_ROW: dual-quaternion weight gradients on the 24-product row kernel
+    bool hcq_no_pool = false;                       // SELD_HCQ_NO_POOL: first stage without the pooling convolution kernel
     bool hcq_no_first = false;                      // SELD_HCQ_NO_FIRST: first layers without the row-walking kernel
     bool wgrad_norow = false, wgrad_slow = false, mha_no_mfma = false;
     int wgrad_cfg = -1;                             // -1 = not forced, else 0..5

@@ -608,6 +608,252 @@ __global__ __launch_bounds__(256, 2) void hcq_first_kernel(const HcqP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// First stage with the pooling decision fused in: conv -> [BatchNorm2d -> ReLU ->] MaxPool2d(8, 1).  BatchNorm + ReLU is
+// z = relu(a y + b) with a = gamma * invstd, and invstd > 0: the SIGN of a is the sign of gamma, known before the batch
+// statistics are.  So the maximum of z over a pooling window sits where y is largest (gamma > 0) or smallest (gamma < 0),
+// and the convolution kernel -- whose workgroup walks exactly the 8 rows of a window -- can pick that element itself:
+// it writes y (the backward pass needs it), the BatchNorm statistics, and per window the chosen raw value + its row.
+// A pooled-size kernel (seld_bn_pool_finish) then applies relu(a v + b) once the statistics are final; the 1.6 GB
+// read-back of y by bn_relu_pool_fwd disappears.  (Ties: where the window's maximum of z is 0 every position ties and
+// torch takes the first; the element chosen here may differ, but ReLU's derivative is 0 there, so no gradient does.
+// gamma == 0 keeps row 0, as torch's first-maximum rule does.)
+//
+// Unlike hcq_first_kernel a wave finishes one channel tile for all 8 rows before the next (the running window maximum of
+// three tiles at once does not fit the register file): 8 accumulators instead of 24, the sums G_m recomputed per tile.
+// ---------------------------------------------------------------------------------------------------------------------
+struct HcqPoolP {
+    const float* gamma;          // (Cdst)
+    float* pool_raw;             // (N, Cdst, Himg / 8, W): the conv output at the window's arg-max / arg-min row
+    unsigned char* idx;          // same shape: that row (0..7)
+};
+
+template <int IBC, int NT1, int NT2, int NR, int R>
+__global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, const HcqPoolP pp) {
+    constexpr int KH = 3, KW = 3, TAPS = 9;
+    constexpr int NT = NT1 + NT2;
+    constexpr int KQ = IBC * TAPS;
+    constexpr int NG = (KQ + 3) / 4;
+    constexpr int NPAIR = (NG + 1) / 2;
+    constexpr int XR = R + KH - 1;
+    static_assert(R == 8, "one workgroup = one MaxPool2d(8, 1) window");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int A = p.A;
+    constexpr int wext = 72, qw = wext >> 2, DPAD = 4;
+
+    const unsigned tiles_per_row = (unsigned)p.W >> 6;
+    const unsigned hblocks = (unsigned)p.Himg / R;
+    unsigned b = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) b = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);     // XCD-contiguous ranges
+    const int w0 = (int)(b % tiles_per_row) * 64;
+    b /= tiles_per_row;
+    const int hq = (int)(b % hblocks);
+    const int h0 = hq * R;
+    const int n_img = (int)(b / hblocks);
+
+    const unsigned S = (unsigned)(p.Himg * p.W);
+    {
+        const unsigned src_bytes = (unsigned)p.N * (unsigned)p.Csrc * S * 4u;
+        const unsigned OOB = 0xFFFFFFF0u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, src_bytes, 0x00020000);
+        const int items = A * IBC * XR * qw;
+        const unsigned img_base = (unsigned)n_img * (unsigned)p.Csrc * S;
+        constexpr float inv_qw = 1.0f / (float)qw;
+        for (int f = tid; f < items; f += 256) {
+            const int row = small_div_h(f, inv_qw);
+            const int quad = f - row * qw;
+            const int ci = row / XR;
+            const int xr = row - ci * XR;
+            const int comp = ci / IBC;
+            const int ibl = ci - comp * IBC;
+            const int hh = h0 - (KH - 1) / 2 + xr;
+            const int ww = w0 - DPAD + 4 * quad;
+            const bool ok = (unsigned)hh < (unsigned)p.Himg && (unsigned)ww < (unsigned)p.W;
+            const unsigned e = img_base + ((unsigned)(comp * p.IB + ibl) * (unsigned)p.Himg + (unsigned)hh) * (unsigned)p.W + (unsigned)ww;
+            const uintx4h v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? e * 4u : OOB, 0, 0);
+            *reinterpret_cast<float4*>(lds + (row * qw + quad) * 4) =
+                make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    }
+    int aoff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int kq = (4 * g + fk) < KQ ? 4 * g + fk : 0;
+        const int ibl = kq / TAPS;
+        const int tap = kq - ibl * TAPS;
+        const int kh = tap / KW;
+        const int kw = tap - kh * KW;
+        aoff[g] = (ibl * XR + kh) * wext + DPAD + wave * 16 + fr + (kw - (KW - 1) / 2);
+    }
+    constexpr int comp_stride = IBC * XR * wext;
+    float* const sred = lds + A * IBC * XR * wext;      // statistics: [tile][wave][component][16 channels][2]
+    const float* const wbase = p.wpack;
+    float* const dst = p.dst[0];
+    const float* const bias = p.bias[0];
+    const bool want_stats = (p.epilogue[0] & SELD_EPI_STATS) != 0;
+    const int grp = fr >> 3;
+    const unsigned img_off = (unsigned)n_img * (unsigned)p.Cdst * S;
+    const unsigned PS = (unsigned)hblocks * (unsigned)p.W;                   // pooled plane
+    const unsigned pool_off = (unsigned)n_img * (unsigned)p.Cdst * PS + (unsigned)hq * (unsigned)p.W +
+                              (unsigned)(w0 + wave * 16 + fk * 4);
+    __syncthreads();
+
+    float2 bfr[8];
+    float gm[2][8];
+    float raw[4];
+    auto read_raw = [&](const float* xs, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[q] = xs[aoff[g] + q * comp_stride];
+    };
+
+    auto tile_body = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int T = decltype(tc)::value;
+        constexpr bool BOTH = NR == 2 && T >= NT1;            // this tile's channels take the second K range too
+        constexpr int NRT = BOTH ? 2 : 1;
+        constexpr int NPCT = NRT * NPAIR;
+        const int ob0 = p.tile_ob[T][grp];
+        const int chb = ob0 >= 0 ? p.tile_half[T][grp] * 4 * p.OB + ob0 + (fr & 7) : -1;
+        // fragments of tile T only: range 0 blocks hold NT tiles per (pair, form, lane), range 1 blocks NT2
+        auto load_b1 = [&](const float* wrow, int rr, int j, int m) __attribute__((always_inline)) {
+            const float* blk = rr == 0 ? wrow : wrow + p.range_stride[0];
+            const int ntr = rr == 0 ? NT : NT2, tt = rr == 0 ? T : T - NT1;
+            bfr[m] = *reinterpret_cast<const float2*>(blk + ((long long)(j * 8 + m) * 64 + lane) * (2 * ntr) + 2 * tt);
+        };
+        float sg[4], yb[4][4], s1[4], s2[4];
+        unsigned bi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float gq = chb >= 0 ? pp.gamma[chb + q * p.OB] : 1.f;
+            sg[q] = gq > 0.f ? 1.f : (gq < 0.f ? -1.f : 0.f);
+            s1[q] = 0.f; s2[q] = 0.f; bi[q] = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yb[q][e] = 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) load_b1(wbase, 0, 0, m);
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {
+            floatx4 acc[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc[m] = (floatx4){0.f, 0.f, 0.f, 0.f};
+            const bool more = r + 1 < R;
+            const float* wrow = wbase;
+            asm volatile("" : "+s"(wrow));               // keep the fragment loads inside the row loop
+            const float* xs0 = lds + r * wext + p.half_src[0] * 4 * comp_stride;
+            const float* xs1 = lds + r * wext + p.half_src[1] * 4 * comp_stride;
+            read_raw(xs0, 0);
+            xforms(raw, gm[0]);
+#pragma unroll
+            for (int s = 0; s < NRT * NG; ++s) {
+                const int rr = s / NG, g = s - rr * NG;
+                const int pc = rr * NPAIR + g / 2;
+                const int gst = s & 1;
+                const bool last = s + 1 == NRT * NG;
+                const bool pair_ends = (g & 1) == 1 || g + 1 == NG;
+                if (!last) {
+                    const int rn = (s + 1) / NG, gn = (s + 1) - rn * NG;
+                    read_raw(rn == 0 ? xs0 : xs1, gn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gm[gst][m], (g & 1) ? bfr[m].y : bfr[m].x, acc[m], 0, 0, 0);
+                    if (pair_ends) {
+                        const int pn = pc + 1;
+                        if (pn < NPCT) load_b1(wrow, pn / NPAIR, pn % NPAIR, m);
+                        else if (more) load_b1(wrow, 0, 0, m);
+                    }
+                }
+                if (!last) xforms(raw, gm[gst ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- this row of this tile: components, store, statistics, window maximum ------------------------------
+            floatx4 c[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h0_ = 0.5f * acc[0][e], h1 = 0.5f * acc[1][e], h2 = 0.5f * acc[2][e], h3 = 0.5f * acc[3][e];
+                c[0][e] = (h3 - h0_) + (h1 + h2) + acc[4][e];
+                c[1][e] = (h3 - h0_) - (h1 + h2) + acc[5][e];
+                c[2][e] = (h3 + h0_) + (h2 - h1) + acc[6][e];
+                c[3][e] = (h3 + h0_) + (h1 - h2) - acc[7][e];
+            }
+            if (chb >= 0) {
+                const unsigned pos_off = (unsigned)(h0 + r) * (unsigned)p.W + (unsigned)(w0 + wave * 16 + fk * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int chn = chb + q * p.OB;
+                    const float bq = bias ? bias[chn] : 0.f;
+                    const float o[4] = {c[q][0] + bq, c[q][1] + bq, c[q][2] + bq, c[q][3] + bq};
+                    *reinterpret_cast<float4*>(dst + img_off + (unsigned)chn * S + pos_off) = make_float4(o[0], o[1], o[2], o[3]);
+                    s1[q] += (o[0] + o[1]) + (o[2] + o[3]);
+                    s2[q] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool take = r == 0 || sg[q] * o[e] > sg[q] * yb[q][e] || o[e] != o[e];
+                        if (take) {
+                            yb[q][e] = o[e];
+                            bi[q] = (bi[q] & ~(0xFFu << (8 * e))) | ((unsigned)r << (8 * e));
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (chb >= 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned po = pool_off + (unsigned)(chb + q * p.OB) * PS;
+                *reinterpret_cast<float4*>(pp.pool_raw + po) = make_float4(yb[q][0], yb[q][1], yb[q][2], yb[q][3]);
+                *reinterpret_cast<unsigned*>(pp.idx + po) = bi[q];
+            }
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a1 = s1[q], a2 = s2[q];
+                a1 += __shfl_xor(a1, 16, 64);
+                a1 += __shfl_xor(a1, 32, 64);
+                a2 += __shfl_xor(a2, 16, 64);
+                a2 += __shfl_xor(a2, 32, 64);
+                if (fk == 0) {
+                    const int slot = ((T * 4 + wave) * 4 + q) * 16 + fr;
+                    sred[slot * 2 + 0] = a1;
+                    sred[slot * 2 + 1] = a2;
+                }
+            }
+        }
+    };
+    tile_body(std::integral_constant<int, 0>{});
+    if constexpr (NT > 1) tile_body(std::integral_constant<int, 1>{});
+    if constexpr (NT > 2) tile_body(std::integral_constant<int, 2>{});
+
+    if (want_stats) {
+        __syncthreads();
+        float* rep = p.stats[0] + (size_t)(blockIdx.x % SELD_STATS_REPLICAS) * 2 * p.Cdst;
+        for (int e = tid; e < NT * 4 * 16; e += 256) {
+            const int fr_ = e & 15, q = (e >> 4) & 3, t = e >> 6;
+            const int g_ = fr_ >> 3;
+            const int ob0 = p.tile_ob[t][g_];
+            if (ob0 < 0) continue;
+            const int chn = (p.tile_half[t][g_] * 4 + q) * p.OB + ob0 + (fr_ & 7);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) {
+                const int slot = ((t * 4 + wv) * 4 + q) * 16 + fr_;
+                a1 += sred[slot * 2 + 0];
+                a2 += sred[slot * 2 + 1];
+            }
+            atomicAdd(rep + chn, a1);
+            atomicAdd(rep + p.Cdst + chn, a2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Weight forms in fragment order.  One thread per packed float.
 //   mode 0 (forward):        dst block channel = conv output block channel, K runs over (conv input block channel, tap)
 //   mode 1 (data gradient):  dst = conv INPUT block channel, K over (conv output block channel, flipped tap), conjugate
@@ -729,8 +975,12 @@ struct HcqPlan {
 
 // mode 0 forward (npair: 1 or 2 convolutions of the same input -> separate outputs),
 // mode 1 data gradient (npair: 1, or 2 = sum of the gradients of two convolutions w.r.t. their common input).
+// mode 2 = mode 0 for the pooling first-stage kernel (hcq_first_pool_kernel): same packed forms, and the 8-channel
+// dual-quaternion layer is NOT left to the short-K kernel.
 static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
     HcqPlan pl{};
+    const bool pool = mode == 2;
+    if (pool) mode = 0;
     const int A = d->algebra;
     if (A != 4 && A != 8) return pl;
     if (d->stride[0] != 1 || d->stride[1] != 1 || d->dil[0] != 1) return pl;
@@ -768,7 +1018,7 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
     // and 688 for hcq_conv_kernel at batch 32; 280 / 287 / 326 at 16.  With two block channels the fast product wins:
     // config 4's 16-channel layer (which does not fit that kernel's LDS) 1303 -> 405 us, config 2's quaternion layer
     // 342 -> 225.
-    if (mode == 0 && taps == 9 && A == 8 && IB == 1 && Cdst == 192 && (long long)d->N * Himg * W >= 256 * 128 &&
+    if (!pool && mode == 0 && taps == 9 && A == 8 && IB == 1 && Cdst == 192 && (long long)d->N * Himg * W >= 256 * 128 &&
         !env().conv_no_smallk) return pl;
     const int rows = A * IBC * KH;
     const int items = rows * (wext / 4);
@@ -842,6 +1092,7 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
         pl.grid = dim3((unsigned)(ptot / 64 / FIRST_R), 1, 1);
         pl.smem = ((size_t)A * IBC * (FIRST_R + 2) * wext + 4 * NT * 4 * 64 * 2) * sizeof(float);   // rows + statistics slots
     }
+    if (pool && (!pl.first_rows || env().hcq_no_pool)) return HcqPlan{};
     pl.ok = 1;
     return pl;
 }
@@ -942,7 +1193,7 @@ static int hcq_launch(const HcqPlan& pl, hipStream_t st) {
 using namespace seld;
 
 extern "C" size_t seld_hcq_pack_floats(const seld_conv_desc* d, int32_t mode, int32_t npair) {
-    if (hc_validate(d) != SELD_OK || (mode != 0 && mode != 1) || npair < 1 || npair > 2) return 0;
+    if (hc_validate(d) != SELD_OK || mode < 0 || mode > 2 || npair < 1 || npair > 2) return 0;
     if (env().conv_no_hcq) return 0;
     const HcqPlan pl = hcq_plan(d, mode, npair);
     HcqKern k;
@@ -957,7 +1208,9 @@ extern "C" int seld_hcq_kernel_label(const seld_conv_desc* d, int32_t mode, int3
     const HcqPlan pl = hcq_plan(d, mode, npair);
     HcqKern k;
     if (!pl.ok || !hcq_pick(pl, &k)) return SELD_EUNSUPPORTED;
-    if (pl.first_rows && hcq_first_takes(pl))        // (label of the plain / statistics epilogue: what the first layer runs)
+    if (mode == 2)
+        snprintf(buf, buflen, "hcq_first_pool_kernel<%d, %d, %d, %d, 8>", k.IBC, k.NT1, k.NT2, k.NR);
+    else if (pl.first_rows && hcq_first_takes(pl))   // (label of the plain / statistics epilogue: what the first layer runs)
         snprintf(buf, buflen, "hcq_first_kernel<%d, %d, %d, %d, %d>", k.IBC, k.NT1, k.NT2, k.NR, pl.first_rows);
     else
         snprintf(buf, buflen, "hcq_conv_kernel<%d, %d, %d, %d, %d, %d, %d>", k.KH, k.KW, k.IBC, k.NT1, k.NT2, k.NR, k.XI);
@@ -968,7 +1221,7 @@ extern "C" int seld_hcq_kernel_label(const seld_conv_desc* d, int32_t mode, int3
 extern "C" int seld_hcq_pack_entry(const seld_conv_desc* d, int32_t mode, int32_t npair, const float* const wA[8],
                                    const float* const wB[8], float* wpack, void* entry) {
     if (hc_validate(d) != SELD_OK || !wA || !wpack || !entry) return SELD_EINVAL;
-    if ((mode != 0 && mode != 1) || npair < 1 || npair > 2 || (npair == 2 && !wB)) return SELD_EINVAL;
+    if (mode < 0 || mode > 2 || npair < 1 || npair > 2 || (npair == 2 && !wB)) return SELD_EINVAL;
     HcqPlan pl = hcq_plan(d, mode, npair);
     if (!pl.ok) return SELD_EUNSUPPORTED;
     for (int i = 0; i < 8; ++i) {
@@ -1025,4 +1278,40 @@ extern "C" int seld_hcq_conv(const seld_conv_desc* d, int32_t mode, int32_t npai
     pl.kp.src2 = x2;
     pl.kp.wpack = wpack;
     return hcq_launch(pl, (hipStream_t)stream);
+}
+
+
+/* conv -> [BatchNorm2d -> ReLU ->] MaxPool2d(8, 1) for the network's first layer (model.py:273-281), pooling decision
+ * inside the convolution (hcq_first_pool_kernel): writes y, the BatchNorm statistics (want_stats), and per pooling window
+ * the raw value at the row that will be the maximum after BatchNorm + ReLU (by the sign of gamma) and that row.
+ * wpack: seld_hcq_pack(desc, mode 2).  Follow with seld_bn_finalize_ex and seld_bn_pool_finish. */
+extern "C" int seld_hcq_first_pool(const seld_conv_desc* d, const float* x, const float* wpack, const float* bias,
+                                   const float* gamma, int32_t want_stats, float* y, float* stats, float* pool_raw,
+                                   uint8_t* idx, void* stream) {
+    if (hc_validate(d) != SELD_OK || !x || !wpack || !gamma || !y || !pool_raw || !idx || (want_stats && !stats)) return SELD_EINVAL;
+    HcqPlan pl = hcq_plan(d, 2, 1);
+    HcqKern k;
+    if (!pl.ok || !hcq_pick(pl, &k) || pl.first_rows != 8) return SELD_EUNSUPPORTED;
+    pl.kp.src = x; pl.kp.src2 = nullptr; pl.kp.wpack = wpack;
+    pl.kp.dst[0] = y; pl.kp.bias[0] = bias; pl.kp.epilogue[0] = want_stats ? SELD_EPI_STATS : 0; pl.kp.stats[0] = stats;
+    const HcqPoolP pp{gamma, pool_raw, idx};
+    const int NT = pl.NT1 + pl.NT2;
+    const size_t smem = ((size_t)pl.kp.A * pl.IBC * 10 * 72 + (size_t)NT * 4 * 4 * 16 * 2) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define SELD_FP(IBC_, NT1_, NT2_, NR_)                                                                                  \
+    do {                                                                                                                \
+        auto kern = hcq_first_pool_kernel<IBC_, NT1_, NT2_, NR_, 8>;                                                    \
+        if (smem > 64 * 1024 &&                                                                                         \
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
+            return SELD_ELAUNCH;                                                                                        \
+        hipLaunchKernelGGL(kern, pl.grid, dim3(256), smem, st, pl.kp, pp);                                              \
+        return check_launch();                                                                                          \
+    } while (0)
+    if (k.IBC == 1) {
+        if (k.NR == 2) { if (k.NT2 == 2) SELD_FP(1, 1, 2, 2); else SELD_FP(1, 1, 1, 2); }
+        if (k.NT1 == 2) SELD_FP(1, 2, 0, 1); else SELD_FP(1, 1, 0, 1);
+    }
+    if (k.NR == 2) { if (k.NT2 == 2) SELD_FP(2, 1, 2, 2); else SELD_FP(2, 1, 1, 2); }
+    if (k.NT1 == 2) SELD_FP(2, 2, 0, 1); else SELD_FP(2, 1, 0, 1);
+#undef SELD_FP
 }

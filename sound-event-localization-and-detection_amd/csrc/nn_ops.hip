@@ -698,6 +698,41 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
 }
 
+// pooled = relu(a * raw + b) on the pooled-size tensor the pooling convolution kernel left (hcq_first_pool_kernel), and --
+// the stage's Dropout (model.py:282) in the same pass -- out = dropout(pooled) with exactly the mask dropout_kernel would
+// draw for the same (seed, offset): group gi = linear element index / 4.  One workgroup per (n, c) plane.
+__global__ __launch_bounds__(256) void bn_pool_finish_kernel(const float* __restrict__ raw, int C, int S,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ pooled, float p, float scale, uint64_t seed,
+                                                             uint64_t offset, const uint64_t* __restrict__ state,
+                                                             float* __restrict__ out) {
+    const int c = blockIdx.x % C;
+    const float a = gamma[c] * invstd[c], b = beta[c] - mean[c] * a;
+    const size_t base = (size_t)blockIdx.x * S;
+    if (out && state) offset += state[0];
+    for (int s = threadIdx.x * 4; s < S; s += 256 * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(raw + base + s);
+        float4 o;
+        o.x = fmaxf(v.x * a + b, 0.f); o.y = fmaxf(v.y * a + b, 0.f);
+        o.z = fmaxf(v.z * a + b, 0.f); o.w = fmaxf(v.w * a + b, 0.f);
+        if (v.x != v.x) o.x = v.x;                                   // NaN propagates (torch's relu / max_pool)
+        if (v.y != v.y) o.y = v.y;
+        if (v.z != v.z) o.z = v.z;
+        if (v.w != v.w) o.w = v.w;
+        *reinterpret_cast<float4*>(pooled + base + s) = o;
+        if (out) {
+            const uint4 r = philox4x32_10(offset + (uint64_t)((base + s) >> 2), seed);
+            float4 d;
+            d.x = u01(r.x) >= p ? o.x * scale : 0.f;
+            d.y = u01(r.y) >= p ? o.y * scale : 0.f;
+            d.z = u01(r.z) >= p ? o.z * scale : 0.f;
+            d.w = u01(r.w) >= p ? o.w * scale : 0.f;
+            *reinterpret_cast<float4*>(out + base + s) = d;
+        }
+    }
+}
+
 __global__ void dropout_mask_rows_kernel(long long rows, float p, float scale, uint64_t seed, uint64_t offset,
                                          const uint64_t* __restrict__ state, float* __restrict__ mask) {
     if (state) offset += state[0];
@@ -1065,6 +1100,16 @@ extern "C" int seld_dropout_fwd(const float* x, int64_t n, float p, uint64_t see
                        1.0f / (1.0f - p), seed, offset, state, y);
     return check_launch();
 }
+extern "C" int seld_bn_pool_finish(const float* raw, int32_t N, int32_t C, int32_t S, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, float* pooled, float p, uint64_t seed,
+                                   uint64_t offset, const uint64_t* state, float* out, void* stream) {
+    if (!raw || !mean || !invstd || !gamma || !beta || !pooled || N <= 0 || C <= 0 || S <= 0 || (S & 3)) return SELD_EINVAL;
+    if (out && (p < 0.f || p >= 1.f)) return SELD_EINVAL;
+    hipLaunchKernelGGL(bn_pool_finish_kernel, dim3((unsigned)(N * C)), dim3(256), 0, ST(stream), raw, C, S, mean, invstd,
+                       gamma, beta, pooled, p, out ? 1.0f / (1.0f - p) : 1.0f, seed, offset, state, out);
+    return check_launch();
+}
+
 extern "C" int seld_dropout_mask_rows(int64_t rows, float p, uint64_t seed, uint64_t offset, const uint64_t* state,
                                       float* mask, void* stream) {
     if (!mask || rows <= 0 || p < 0.f || p >= 1.f) return SELD_EINVAL;

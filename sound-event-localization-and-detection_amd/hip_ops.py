@@ -1640,24 +1640,60 @@ class ConvBnReluPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, gamma, beta, running_mean, running_var, training, momentum, eps, ph, nbt, stride, padding,
-                dilation, *ws):
+                dilation, drop_p, *ws):
         algebra = len(ws)
+        ctx.rng = None
         k = tuple(ws[0].shape[2:])
         desc = make_conv_desc(tuple(x.shape), ws[0].shape[0] * algebra, algebra, k, stride, padding, dilation)
         x = _req(x, "x")
         stats = new_stats(desc.Cout, x.device) if training else None
-        y = conv_fwd(desc, x, ws, bias, epilogue=L.SELD_EPI_STATS if training else 0, stats=stats)
-        N, C, Hh, Ww = y.shape
-        mean, invstd = bn_prepare(y, running_mean, running_var, training, momentum, eps, stats, nbt)
-        pooled = torch.empty((N, C, Hh // ph, Ww), device=y.device, dtype=torch.float32)
-        idx = torch.empty(pooled.shape, device=y.device, dtype=torch.uint8)
-        L.check(L.lib().seld_bn_relu_pool_fwd(L.ptr(y), N, C, Hh, Ww, ph, 1, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-                                              L.ptr(beta), L.ptr(pooled), L.ptr(idx), L.current_stream()),
-                "seld_bn_relu_pool_fwd")
+        wp = hcq_weights.get(desc, 2, ws) if (ph == 8 and algebra > 1) else None
+        if wp is not None:
+            # the convolution picks every pooling window's element itself (by the sign of gamma): y is written for the
+            # backward pass but never read back in the forward pass (csrc/hcq_conv.hip hcq_first_pool_kernel)
+            o = conv_out_shape(desc)
+            y = torch.empty(_y_shape(desc, o), device=x.device, dtype=torch.float32)
+            N, C, Hh, Ww = y.shape
+            raw = torch.empty((N, C, Hh // ph, Ww), device=x.device, dtype=torch.float32)
+            idx = torch.empty(raw.shape, device=x.device, dtype=torch.uint8)
+            with _Timed(desc, 0, label=_hcq_label_cached(desc, 2, 1) if kernel_timer.active else None):
+                L.check(L.lib().seld_hcq_first_pool(ctypes.byref(desc), L.ptr(x), L.ptr(wp), L.ptr(_req(bias, "bias")),
+                                                    L.ptr(gamma), int(training), L.ptr(y), L.ptr(stats), L.ptr(raw),
+                                                    L.ptr(idx), L.current_stream()), "seld_hcq_first_pool")
+            mean, invstd = bn_prepare(y, running_mean, running_var, training, momentum, eps, stats, nbt)
+            pooled = torch.empty_like(raw)
+            out = None
+            p_, seed, off, state = 0.0, 0, 0, None
+            if drop_p > 0.0:           # the stage's Dropout in the same pass (same mask as a DropoutFn at this point would draw)
+                p_ = float(drop_p)
+                seed, off, state = philox.draw((pooled.numel() + 3) // 4, x.device)
+                out = torch.empty_like(raw)
+                ctx.rng = (p_, seed, off, state)
+            L.check(L.lib().seld_bn_pool_finish(L.ptr(raw), N, C, (Hh // ph) * Ww, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                                L.ptr(beta), L.ptr(pooled), ctypes.c_float(p_), ctypes.c_uint64(seed),
+                                                ctypes.c_uint64(off), L.ptr(state), L.ptr(out), L.current_stream()),
+                    "seld_bn_pool_finish")
+        else:
+            y = conv_fwd(desc, x, ws, bias, epilogue=L.SELD_EPI_STATS if training else 0, stats=stats)
+            N, C, Hh, Ww = y.shape
+            mean, invstd = bn_prepare(y, running_mean, running_var, training, momentum, eps, stats, nbt)
+            pooled = torch.empty((N, C, Hh // ph, Ww), device=y.device, dtype=torch.float32)
+            idx = torch.empty(pooled.shape, device=y.device, dtype=torch.uint8)
+            L.check(L.lib().seld_bn_relu_pool_fwd(L.ptr(y), N, C, Hh, Ww, ph, 1, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                                  L.ptr(beta), L.ptr(pooled), L.ptr(idx), L.current_stream()),
+                    "seld_bn_relu_pool_fwd")
+            out = None
+            if drop_p > 0.0:
+                seed, off, state = philox.draw((pooled.numel() + 3) // 4, x.device)
+                out = torch.empty_like(pooled)
+                L.check(L.lib().seld_dropout_fwd(L.ptr(pooled), ctypes.c_int64(pooled.numel()), ctypes.c_float(drop_p),
+                                                 ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(state), L.ptr(out),
+                                                 L.current_stream()), "seld_dropout_fwd")
+                ctx.rng = (float(drop_p), seed, off, state)
         ctx.desc, ctx.geom = desc, (N, C, Hh, Ww, ph, training)
         ctx.params = (ws, bias, gamma, beta)
         ctx.save_for_backward(x, y, pooled, idx, mean, invstd)
-        return pooled
+        return pooled if out is None else out
 
     @staticmethod
     def backward(ctx, dpooled):
@@ -1665,6 +1701,13 @@ class ConvBnReluPoolFn(torch.autograd.Function):
         ws, bias, gamma, beta = ctx.params
         N, C, Hh, Ww, ph, training = ctx.geom
         dpooled = _req(dpooled, "dpooled")
+        if ctx.rng is not None:                     # through the Dropout: the same mask
+            p_, seed, off, state = ctx.rng
+            dp = torch.empty_like(dpooled)
+            L.check(L.lib().seld_dropout_fwd(L.ptr(dpooled), ctypes.c_int64(dpooled.numel()), ctypes.c_float(p_),
+                                             ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(state), L.ptr(dp),
+                                             L.current_stream()), "seld_dropout_fwd")
+            dpooled = dp
         direct = _direct_targets(ws, bias)
         if direct is None:
             raise L.SeldHipError("ConvBnReluPoolFn needs gradient slots (FlatAdam); use hyper_conv_stats + bn_relu_pool")
@@ -1686,12 +1729,14 @@ class ConvBnReluPoolFn(torch.autograd.Function):
             dg, db = red[:C], red[C:]
         elif not clean:
             axpy_(slot, red, 2 * C)
-        return (None, None, dg, db) + (None,) * (10 + len(ws))
+        return (None, None, dg, db) + (None,) * (11 + len(ws))
 
 
-def conv_bn_relu_pool(x, ws, bias, bn, ph, pw, stride, padding, dilation):
-    """conv -> BatchNorm2d -> ReLU -> MaxPool2d(ph, pw).  The first stage of the network (x needs no gradient) takes the
-    fused backward above when the shape qualifies; everything else is hyper_conv[_stats] + bn_relu_pool."""
+def conv_bn_relu_pool(x, ws, bias, bn, ph, pw, stride, padding, dilation, drop_p=0.0):
+    """conv -> BatchNorm2d -> ReLU -> MaxPool2d(ph, pw) [-> Dropout(drop_p), training mode].  The first stage of the
+    network (x needs no gradient) takes the fused forms above when the shape qualifies; everything else is
+    hyper_conv[_stats] + bn_relu_pool + dropout."""
+    drop_p = float(drop_p) if bn.training else 0.0
     k = tuple(ws[0].shape[2:])
     one = lambda v: v == 1 or tuple(v) == (1, 1) if isinstance(v, (tuple, list)) else v == 1
     fused = (not x.requires_grad and torch.is_grad_enabled() and x.dim() == 4 and k == (3, 3) and int(pw) == 1 and
@@ -1703,9 +1748,9 @@ def conv_bn_relu_pool(x, ws, bias, bn, ph, pw, stride, padding, dilation):
     if fused:
         return ConvBnReluPoolFn.apply(x, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
                                       bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(ph), _nbt(bn),
-                                      stride, padding, dilation, *ws)
+                                      stride, padding, dilation, drop_p, *ws)
     if bn.training:
         y, stats = hyper_conv_stats(x, ws, bias, stride, padding, dilation)
     else:
         y, stats = hyper_conv(x, ws, bias, stride, padding, dilation), None
-    return bn_relu_pool(y, bn, ph, pw, stats)
+    return dropout(bn_relu_pool(y, bn, ph, pw, stats), drop_p, bn.training)

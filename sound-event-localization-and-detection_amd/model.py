@@ -268,8 +268,13 @@ class _CnnStage(nn.Sequential):
             bn, pool = mods[1], mods[3]
             s, p, d = _geom(conv)
             ph, pw = hnn._window(pool.kernel_size, 2)
+            drop = mods[4]
+            if isinstance(drop, hnn.Dropout) and drop.training == bn.training:
+                # the stage's Dropout rides in the pooled-size pass of the fused first stage (same mask, same draw order)
+                return H.conv_bn_relu_pool(x, _components(conv), conv.bias, bn, ph, pw, s, p, d,
+                                           drop_p=drop.p if drop.training else 0.0)
             x = H.conv_bn_relu_pool(x, _components(conv), conv.bias, bn, ph, pw, s, p, d)
-            return mods[4](x)
+            return drop(x)
         x = conv(x)
         for m in mods[1:]:
             x = m(x)

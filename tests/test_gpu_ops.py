@@ -431,6 +431,10 @@ def test_first_stage_fused_backward(algebra, cin, cout, hw, ph, training, monkey
     ws0 = [torch.randn(cout // algebra, cin // algebra, 3, 3, generator=gen) * 0.3 for _ in range(algebra)]
     b0 = torch.randn(cout, generator=gen) * 0.1
     g0, be0 = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.2
+    # negative and zero BatchNorm weights: the pooling convolution kernel (hcq_first_pool_kernel) picks a window's element by
+    # the sign of gamma -- largest conv output, smallest, or (gamma == 0: everything ties) the first row
+    g0[1::3] *= -1.0
+    g0[5] = 0.0
     cot = torch.randn(3, cout, hw[0] // ph, hw[1], generator=gen)
 
     def run(fused):
@@ -473,6 +477,47 @@ def test_first_stage_fused_backward(algebra, cin, cout, hw, ph, training, monkey
     _close(got[4], be64.grad, rel=5e-4, what="dbeta vs fp64")
     scale = max(float(w64[0].grad.abs().max()), 1e-6)
     assert float((got[2].double() - b64.grad).abs().max()) < 1e-3 * scale * cot.numel() ** 0.5     # ~0 under batch statistics
+
+
+@pytest.mark.parametrize("cin,hw", [(8, (16, 64)), (16, (8, 128)), (8, (16, 96))])
+def test_first_stage_dropout_in_the_pooled_pass(cin, hw):
+    """The stage's Dropout fused into the first stage (seld_bn_pool_finish on the pooling-convolution path, a dropout
+    launch inside the function otherwise) against conv_bn_relu_pool followed by a separate dropout at the same Philox
+    offset: same mask, same outputs, same gradients."""
+    P = pkg()
+    H, T = P.hip_ops, P.train
+    cout, ph = 192, 8
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(2, cin, *hw, generator=gen)
+    ws0 = [torch.randn(cout // 8, cin // 8, 3, 3, generator=gen) * 0.3 for _ in range(8)]
+    g0 = torch.rand(cout, generator=gen) - 0.4
+    cot = torch.randn(2, cout, hw[0] // ph, hw[1], generator=gen)
+
+    def run(fused_dropout):
+        ws = [torch.nn.Parameter(w.clone().to(DEV)) for w in ws0]
+        bn = P.hip_nn.BatchNorm2d(cout).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(g0.to(DEV))
+        opt = T.FlatAdam(ws + list(bn.parameters()), lr=1e-3)
+        opt.zero_grad()
+        H.philox.set_offset(1000)
+        if fused_dropout:
+            y = H.conv_bn_relu_pool(x.to(DEV), ws, None, bn, ph, 1, 1, 1, 1, drop_p=0.3)
+        else:
+            y = H.dropout(H.conv_bn_relu_pool(x.to(DEV), ws, None, bn, ph, 1, 1, 1, 1), 0.3, True)
+        (y * cot.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().cpu(), [w.grad.detach().cpu().clone() for w in ws], bn.weight.grad.cpu().clone(), H.philox.offset
+
+    got, ref = run(True), run(False)
+    assert got[3] == ref[3]                                   # the same number of draws
+    zero = (ref[0] == 0)
+    assert 0.2 < float(zero.float().mean()) < 0.9             # dropout really happened (ReLU zeros on top of p = 0.3)
+    assert torch.equal(got[0] == 0, zero)
+    _close(got[0], ref[0], rel=1e-6, what="dropped output")
+    for a, b in zip(got[1], ref[1]):
+        _close(a, b, rel=2e-4, what="dw")
+    _close(got[2], ref[2], rel=1e-5, what="dgamma")
 
 
 # ------------------------------------------------------------------------------------------
