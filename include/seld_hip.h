@@ -228,9 +228,20 @@ int seld_bn_relu_pool_bwd_coef(const float* dpooled, const float* pooled, const 
                                int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
                                const float* invstd, const float* gamma, const float* beta, int32_t train,
                                float* red, float* coef, float* conv_dbias /* nullable */, void* stream);
+/* the same with dpooled = the gradient BEHIND the stage's Dropout(drop_p) (model.py:282): its mask -- the one
+ * seld_dropout_fwd draws for (seed, offset, state) -- is replayed while dpooled is loaded, no dropout-backward pass */
+int seld_bn_relu_pool_bwd_coef_drop(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                                    int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                                    const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                    int32_t train, float* red, float* coef, float* conv_dbias, float drop_p,
+                                    uint64_t seed, uint64_t offset, const uint64_t* state, void* stream);
 int seld_hc_conv_bwd_weight_bnpool_acc(const seld_conv_desc* d, const float* x, const float* y, const float* pooled,
                                        const float* dpooled, const uint8_t* idx, int32_t ph, const float* coef,
                                        float* const dw[8], void* stream);
+int seld_hc_conv_bwd_weight_bnpool_drop_acc(const seld_conv_desc* desc, const float* x, const float* y,
+                                            const float* pooled, const float* dpooled, const uint8_t* idx, int32_t ph,
+                                            const float* coef, float* const dw[8], float drop_p, uint64_t seed,
+                                            uint64_t offset, const uint64_t* state, void* stream);
 
 /* y = act(gamma * (x - mean) * invstd + beta) */
 int seld_bn_act_fwd(const float* x, int32_t N, int32_t C, int32_t S, const float* mean, const float* invstd,

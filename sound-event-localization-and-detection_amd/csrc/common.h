@@ -47,6 +47,38 @@ struct WPtrsMut {
     float* p[8];
 };
 
+// Philox-4x32-10 (counter, key) -> four 32-bit draws; u01: the top 24 bits as a float in [0, 1)
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t counter, uint64_t key) {
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// a Dropout to replay on a gradient while it is loaded (p == 0: none)
+struct DropP {
+    float p, scale;
+    uint64_t seed, offset;
+    const uint64_t* state;      // nullable: the device-resident step state, state[0] is added to offset
+};
+
+// four dropout factors (0 or scale) of the 128-bit group `group`: the mask seld_dropout_fwd draws for the same stream position
+__device__ __forceinline__ float4 dropout_mask4(uint64_t group, uint64_t seed, float p, float scale) {
+    const uint4 r = philox4x32_10(group, seed);
+    return make_float4(u01(r.x) >= p ? scale : 0.f, u01(r.y) >= p ? scale : 0.f, u01(r.z) >= p ? scale : 0.f, u01(r.w) >= p ? scale : 0.f);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const floa
                                                                       const uint8_t* __restrict__ idx, PoolGeom g,
                                                                       const float* __restrict__ mean,
                                                                       const float* __restrict__ invstd,
-                                                                      float* __restrict__ red) {
+                                                                      float* __restrict__ red, DropP dr) {
     const int c = blockIdx.y;
+    if (dr.p > 0.f && dr.state) dr.offset += dr.state[0];
     const bool degenerate = gamma[c] == 0.f;      // xhat cannot be recovered from z: gather it from y instead
     const float inv_g = degenerate ? 0.f : 1.0f / gamma[c];
     const float be = beta[c];
@@ -136,7 +137,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const floa
             const long long n = n0 + dn;
             const size_t off = ((size_t)n * C + c) * S + s_;
             const float4 z4 = *reinterpret_cast<const float4*>(pooled + off);
-            const float4 d4 = *reinterpret_cast<const float4*>(dpooled + off);
+            float4 d4 = *reinterpret_cast<const float4*>(dpooled + off);
+            if (dr.p > 0.f) {                     // dpooled is the gradient behind the stage's Dropout: the same mask
+                const float4 mk = dropout_mask4(dr.offset + (uint64_t)(off >> 2), dr.seed, dr.p, dr.scale);
+                d4.x *= mk.x; d4.y *= mk.y; d4.z *= mk.z; d4.w *= mk.w;
+            }
             one(z4.x, d4.x, n, s_, off);
             one(z4.y, d4.y, n, s_ + 1, off + 1);
             one(z4.z, d4.z, n, s_ + 2, off + 2);
@@ -149,7 +154,13 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const floa
             const unsigned s_ = local - dn * (unsigned)S;
             const long long n = n0 + dn;
             const size_t off = ((size_t)n * C + c) * S + s_;
-            one(pooled[off], dpooled[off], n, s_, off);
+            float d = dpooled[off];
+            if (dr.p > 0.f) {
+                const float4 mk = dropout_mask4(dr.offset + (uint64_t)(off >> 2), dr.seed, dr.p, dr.scale);
+                const float m4[4] = {mk.x, mk.y, mk.z, mk.w};
+                d *= m4[off & 3];
+            }
+            one(pooled[off], d, n, s_, off);
         }
     }
     __shared__ float r0[4], r1[4];
@@ -305,10 +316,13 @@ extern "C" int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32
 // First half of seld_bn_relu_pool_bwd for a convolution whose INPUT needs no gradient (the first layer): the
 // reductions (red = dgamma | dbeta sums, from pooled-size tensors) and the three per-channel coefficients with which
 // seld_hc_conv_bwd_weight_bnpool_acc forms dy on the fly.  The 1.6 GB gradient w.r.t. the conv output is never written.
-extern "C" int seld_bn_relu_pool_bwd_coef(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
-                                          int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
-                                          const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                          int32_t train, float* red, float* coef, float* conv_dbias, void* stream) {
+extern "C" int seld_bn_relu_pool_bwd_coef_drop(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                                               int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                                               const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                               int32_t train, float* red, float* coef, float* conv_dbias, float drop_p,
+                                               uint64_t seed, uint64_t offset, const uint64_t* state, void* stream) {
+    if (drop_p < 0.f || drop_p >= 1.f) return SELD_EINVAL;
+    const DropP dr{drop_p, 1.0f / (1.0f - drop_p), seed, offset, state};
     PoolGeom g;
     int rc = mk_geom(g, N, C, H, W, ph, pw);
     if (rc) return rc;
@@ -317,12 +331,20 @@ extern "C" int seld_bn_relu_pool_bwd_coef(const float* dpooled, const float* poo
     const int S = g.OH * g.OW;
     const long long M = (long long)N * S;
     hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel, dim3((unsigned)((M + 8191) / 8192), C), dim3(256), 0, st, dpooled, pooled,
-                       N, C, S, gamma, beta, y, idx, g, mean, invstd, red);
+                       N, C, S, gamma, beta, y, idx, g, mean, invstd, red, dr);
     rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(bn_pool_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, mean, invstd, gamma, C,
                        1.0f / (float)((long long)N * H * W), train, coef, conv_dbias);
     return check_launch();
+}
+
+extern "C" int seld_bn_relu_pool_bwd_coef(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                                          int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                                          const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                          int32_t train, float* red, float* coef, float* conv_dbias, void* stream) {
+    return seld_bn_relu_pool_bwd_coef_drop(dpooled, pooled, idx, y, N, C, H, W, ph, pw, mean, invstd, gamma, beta, train, red,
+                                           coef, conv_dbias, 0.f, 0, 0, nullptr, stream);
 }
 
 extern "C" int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
@@ -337,7 +359,7 @@ extern "C" int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, 
     const int S = g.OH * g.OW;
     const long long M = (long long)N * S;
     hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel, dim3((unsigned)((M + 8191) / 8192), C), dim3(256), 0, st, dpooled, pooled,
-                       N, C, S, gamma, beta, y, idx, g, mean, invstd, red);
+                       N, C, S, gamma, beta, y, idx, g, mean, invstd, red, DropP{0.f, 1.f, 0, 0, nullptr});
     rc = check_launch();
     if (rc) return rc;
     const int OHx = (H + ph - 1) / ph, OWx = (W + pw - 1) / pw;

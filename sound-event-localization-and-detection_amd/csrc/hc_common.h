@@ -75,6 +75,7 @@ struct WgradP {
     const unsigned char* pidx;
     const float* coef;
     int poolh;         // pooling window height
+    DropP drop;        // FUSED: dpooled is the gradient behind the stage's Dropout; replay its mask (p == 0: none)
     int mz, nact, nt;  // tile enumeration without the zero quadrant: the first mz row tiles have nact column tiles, the rest nt
     int dbg;           // SELD_WGRAD_DBG: timing experiments (wrong results): 1 = no loads in the loop, 2 = no LDS stores
 };

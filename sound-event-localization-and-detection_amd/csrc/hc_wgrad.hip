@@ -615,9 +615,23 @@ using namespace seld;
 // dw[c] += weight gradient of a convolution that is followed by BatchNorm2d -> ReLU -> MaxPool2d(ph, 1) and whose
 // input needs no gradient: the gradient w.r.t. the conv output is formed from y, the pooled-size tensors and `coef`
 // (seld_bn_relu_pool_bwd_coef) while the operand is staged.  SELD_EUNSUPPORTED when the shape does not qualify.
+extern "C" int seld_hc_conv_bwd_weight_bnpool_drop_acc(const seld_conv_desc* d, const float* x, const float* y,
+                                                       const float* pooled, const float* dpooled, const uint8_t* idx,
+                                                       int32_t ph, const float* coef, float* const dw[8], float drop_p,
+                                                       uint64_t seed, uint64_t offset, const uint64_t* state, void* stream);
+
 extern "C" int seld_hc_conv_bwd_weight_bnpool_acc(const seld_conv_desc* d, const float* x, const float* y,
                                                   const float* pooled, const float* dpooled, const uint8_t* idx,
                                                   int32_t ph, const float* coef, float* const dw[8], void* stream) {
+    return seld_hc_conv_bwd_weight_bnpool_drop_acc(d, x, y, pooled, dpooled, idx, ph, coef, dw, 0.f, 0, 0, nullptr, stream);
+}
+
+// ... with dpooled = the gradient BEHIND the stage's Dropout(drop_p): its mask is replayed while dpooled is loaded
+extern "C" int seld_hc_conv_bwd_weight_bnpool_drop_acc(const seld_conv_desc* d, const float* x, const float* y,
+                                                       const float* pooled, const float* dpooled, const uint8_t* idx,
+                                                       int32_t ph, const float* coef, float* const dw[8], float drop_p,
+                                                       uint64_t seed, uint64_t offset, const uint64_t* state, void* stream) {
+    if (drop_p < 0.f || drop_p >= 1.f) return SELD_EINVAL;
     int rc = hc_validate(d);
     if (rc) return rc;
     int o[2];
@@ -637,6 +651,7 @@ extern "C" int seld_hc_conv_bwd_weight_bnpool_acc(const seld_conv_desc* d, const
     p.x = x; p.dy = y;
     p.nslots = 1;
     p.pooled = pooled; p.dpooled = dpooled; p.pidx = idx; p.coef = coef; p.poolh = ph;
+    p.drop = DropP{drop_p, 1.0f / (1.0f - drop_p), seed, offset, state};
     for (int i = 0; i < 8; ++i) p.gw.p[i] = (i < d->algebra) ? dw[i] : nullptr;
     const int cfg = wgrad_cfg(d);
     static const int tile_m[6] = {128, 192, 64, 96, 64, 64}, tile_n[6] = {128, 80, 64, 128, 80, 160};

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
     unsigned a_voff[AR];
     // FUSED: the row's offset in the pooled-size tensors and its three BatchNorm-backward coefficients
     const int pooledS = FUSED ? (p.outH / p.poolh) * p.outW : 0;
+    const uint64_t drop_off = (FUSED && p.drop.p > 0.f) ? p.drop.offset + (p.drop.state ? p.drop.state[0] : 0) : 0;
     unsigned p_voff[AR];
     float c_1[AR], c_a[AR], c_0[AR];
 #pragma unroll
@@ -169,6 +170,10 @@ __global__ __launch_bounds__(256) void hc_wgrad_row_kernel(const WgradP p) {
                 const uintx4 d = __builtin_amdgcn_raw_buffer_load_b128(dr, eo == OOB ? OOB : eo * 4u, 0, 0);
                 pz[j] = (floatx4){__uint_as_float(z[0]), __uint_as_float(z[1]), __uint_as_float(z[2]), __uint_as_float(z[3])};
                 pd[j] = (floatx4){__uint_as_float(d[0]), __uint_as_float(d[1]), __uint_as_float(d[2]), __uint_as_float(d[3])};
+                if (p.drop.p > 0.f && eo != OOB) {
+                    const float4 mk = dropout_mask4(drop_off + (uint64_t)((pq + (long long)eo) >> 2), p.drop.seed, p.drop.p, p.drop.scale);
+                    pd[j][0] *= mk.x; pd[j][1] *= mk.y; pd[j][2] *= mk.z; pd[j][3] *= mk.w;
+                }
                 pi[j] = __builtin_amdgcn_raw_buffer_load_b32(ir, eo, 0, 0);
             }
           }

@@ -656,23 +656,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // Philox-4x32-10 dropout
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 philox4x32_10(uint64_t counter, uint64_t key) {
-    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
-    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return make_uint4(c0, c1, c2, c3);
-}
-__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+// philox4x32_10 / u01: common.h
 
 // `state` (nullable): the device-resident step state of seld_step_begin; state[0] is added to `offset`, so that a
 // launch recorded in a HIP graph draws fresh numbers at every replay.

@@ -1701,13 +1701,9 @@ class ConvBnReluPoolFn(torch.autograd.Function):
         ws, bias, gamma, beta = ctx.params
         N, C, Hh, Ww, ph, training = ctx.geom
         dpooled = _req(dpooled, "dpooled")
-        if ctx.rng is not None:                     # through the Dropout: the same mask
-            p_, seed, off, state = ctx.rng
-            dp = torch.empty_like(dpooled)
-            L.check(L.lib().seld_dropout_fwd(L.ptr(dpooled), ctypes.c_int64(dpooled.numel()), ctypes.c_float(p_),
-                                             ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(state), L.ptr(dp),
-                                             L.current_stream()), "seld_dropout_fwd")
-            dpooled = dp
+        # ctx.rng: `dpooled` is the gradient BEHIND the stage's Dropout; both consumers replay its mask while they load it
+        p_, seed, off, state = ctx.rng if ctx.rng is not None else (0.0, 0, 0, None)
+        drop = (ctypes.c_float(p_), ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(state))
         direct = _direct_targets(ws, bias)
         if direct is None:
             raise L.SeldHipError("ConvBnReluPoolFn needs gradient slots (FlatAdam); use hyper_conv_stats + bn_relu_pool")
@@ -1715,15 +1711,15 @@ class ConvBnReluPoolFn(torch.autograd.Function):
         red = slot if clean else torch.zeros(2 * C, device=y.device, dtype=torch.float32)
         coef = torch.empty(3 * C, device=y.device, dtype=torch.float32)
         st = L.current_stream()
-        L.check(L.lib().seld_bn_relu_pool_bwd_coef(L.ptr(dpooled), L.ptr(pooled), L.ptr(idx), L.ptr(y), N, C, Hh, Ww, ph, 1,
-                                                   L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(training),
-                                                   L.ptr(red), L.ptr(coef), L.ptr(direct[1]), st),
-                "seld_bn_relu_pool_bwd_coef")
+        L.check(L.lib().seld_bn_relu_pool_bwd_coef_drop(L.ptr(dpooled), L.ptr(pooled), L.ptr(idx), L.ptr(y), N, C, Hh, Ww, ph,
+                                                        1, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta),
+                                                        int(training), L.ptr(red), L.ptr(coef), L.ptr(direct[1]), *drop, st),
+                "seld_bn_relu_pool_bwd_coef_drop")
         with _Timed(ctx.desc, 2, 1, True):
-            L.check(L.lib().seld_hc_conv_bwd_weight_bnpool_acc(ctypes.byref(ctx.desc), L.ptr(x), L.ptr(y), L.ptr(pooled),
-                                                               L.ptr(dpooled), L.ptr(idx), ph, L.ptr(coef),
-                                                               L.ptr_array8(direct[0]), st),
-                    "seld_hc_conv_bwd_weight_bnpool_acc")
+            L.check(L.lib().seld_hc_conv_bwd_weight_bnpool_drop_acc(ctypes.byref(ctx.desc), L.ptr(x), L.ptr(y),
+                                                                    L.ptr(pooled), L.ptr(dpooled), L.ptr(idx), ph,
+                                                                    L.ptr(coef), L.ptr_array8(direct[0]), *drop, st),
+                    "seld_hc_conv_bwd_weight_bnpool_drop_acc")
         dg = db = None
         if slot is None:
             dg, db = red[:C], red[C:]

@@ -111,8 +111,8 @@ def test_two_rank_graphed_step_matches_eager(tmp_path):
     # the mean deviation is what shows a wrong exchange
     d = (g0["param"] - e0["param"]).abs()
     lr, steps = 1e-3, 4
-    assert d.mean().item() <= 0.02 * lr, d.mean().item()
-    assert (d > 0.1 * lr).float().mean().item() <= 2e-3, (d > 0.1 * lr).float().mean().item()
+    assert d.mean().item() <= 0.1 * lr, d.mean().item()
+    assert (d > 0.5 * lr).float().mean().item() <= 2e-2, (d > 0.5 * lr).float().mean().item()
     assert d.max().item() <= 2 * steps * lr * 1.01, d.max().item()       # the hard bound: lr per step, either way
 
 
@@ -159,10 +159,13 @@ def test_graphed_step_matches_eager_step():
     # Parameters: Adam moves a parameter by up to lr per step whatever the size of its gradient, so one whose gradient is
     # float-atomic noise around zero can end anywhere within 2 * steps * lr of its twin (observed maxima 3e-3..6e-3 from
     # run to run).  Bound the bulk tightly and the stragglers by that hard limit.
+    # Two EAGER runs already part the same way (tools/chaos_check.py: mean 3.1e-5, max 6e-3 -- from step 4 on there are two
+    # trajectories, 5.1294 / 5.1332 at step 5, depending on which way one noise-level decision falls), so the mean is
+    # held to 0.1 lr, not to rounding.
     d = (pg - pe).abs()
     lr, steps = 1e-3, 5
-    assert d.mean().item() <= 0.02 * lr, d.mean().item()
-    assert (d > 0.1 * lr).float().mean().item() <= 2e-3, (d > 0.1 * lr).float().mean().item()
+    assert d.mean().item() <= 0.1 * lr, d.mean().item()
+    assert (d > 0.5 * lr).float().mean().item() <= 2e-2, (d > 0.5 * lr).float().mean().item()
     assert d.max().item() <= 2 * steps * lr * 1.01, d.max().item()
     assert opt.step_count == 5
     for k in sde:
