@@ -419,7 +419,9 @@ def test_spectrum_fast_full_clip():
 
 @pytest.mark.parametrize("algebra,cin,cout,hw,ph,training", [(8, 8, 192, (16, 64), 8, True), (4, 8, 64, (8, 32), 2, True),
                                                              (8, 8, 64, (16, 96), 8, False),
-                                                             (8, 16, 192, (16, 64), 8, True)])   # K = 144: 64 x 160 tiles
+                                                             (8, 16, 192, (16, 64), 8, True),    # K = 144: 64 x 160 tiles
+                                                             (4, 8, 64, (16, 64), 8, True),      # quaternion, pooling convolution
+                                                             (4, 8, 128, (8, 128), 8, False)])   # ... two tiles, eval statistics
 def test_first_stage_fused_backward(algebra, cin, cout, hw, ph, training, monkeypatch):
     """conv -> BatchNorm2d -> ReLU -> MaxPool(ph, 1) on an input that needs no gradient: the fused backward
     (seld_bn_relu_pool_bwd_coef + seld_hc_conv_bwd_weight_bnpool_acc, dy never written) against the unfused path
