@@ -691,6 +691,11 @@ __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, co
     }
     constexpr int comp_stride = IBC * XR * wext;
     float* const sred = lds + A * IBC * XR * wext;      // statistics: [tile][wave][component][16 channels][2]
+    // The current tile's weight fragments live in LDS ([pair][form][lane] float2): with them in global memory every row
+    // ended on `s_waitcnt vmcnt` for its fragment loads -- and loads and stores retire in order on one counter, so each
+    // row also waited for the previous row's 12 stores to reach memory: store time ADDED to compute time (686 us).  With no
+    // global load inside the row loop the stores drain under the next rows' MFMAs.
+    float2* const wl = reinterpret_cast<float2*>(sred + NT * 4 * 4 * 16 * 2);
     const float* const wbase = p.wpack;
     float* const dst = p.dst[0];
     const float* const bias = p.bias[0];
@@ -717,32 +722,36 @@ __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, co
         constexpr int NPCT = NRT * NPAIR;
         const int ob0 = p.tile_ob[T][grp];
         const int chb = ob0 >= 0 ? p.tile_half[T][grp] * 4 * p.OB + ob0 + (fr & 7) : -1;
-        // fragments of tile T only: range 0 blocks hold NT tiles per (pair, form, lane), range 1 blocks NT2
-        auto load_b1 = [&](const float* wrow, int rr, int j, int m) __attribute__((always_inline)) {
-            const float* blk = rr == 0 ? wrow : wrow + p.range_stride[0];
+        // fragments of tile T only (range 0 blocks hold NT tiles per (pair, form, lane), range 1 blocks NT2): into LDS
+        __syncthreads();                                  // everybody is done with the previous tile's fragments
+        for (int e = tid; e < NPCT * 8 * 64; e += 256) {
+            const int ln = e & 63, jm = e >> 6;           // jm = pair * 8 + form over both ranges
+            const int rr = jm / (NPAIR * 8), jm0 = jm - rr * (NPAIR * 8);
+            const float* blk = rr == 0 ? wbase : wbase + p.range_stride[0];
             const int ntr = rr == 0 ? NT : NT2, tt = rr == 0 ? T : T - NT1;
-            bfr[m] = *reinterpret_cast<const float2*>(blk + ((long long)(j * 8 + m) * 64 + lane) * (2 * ntr) + 2 * tt);
-        };
-        float sg[4], yb[4][4], s1[4], s2[4];
+            wl[e] = *reinterpret_cast<const float2*>(blk + ((long long)jm0 * 64 + ln) * (2 * ntr) + 2 * tt);
+        }
+        __syncthreads();
+        auto load_b1 = [&](int pc, int m) __attribute__((always_inline)) { bfr[m] = wl[(pc * 8 + m) * 64 + lane]; };
+        float sg[4], yb[4][4], sb[4][4], s1[4], s2[4], bq[4];     // sb = sg * yb, the key the window maximum is taken over
         unsigned bi[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float gq = chb >= 0 ? pp.gamma[chb + q * p.OB] : 1.f;
+            bq[q] = (bias && chb >= 0) ? bias[chb + q * p.OB] : 0.f;
             sg[q] = gq > 0.f ? 1.f : (gq < 0.f ? -1.f : 0.f);
             s1[q] = 0.f; s2[q] = 0.f; bi[q] = 0u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) yb[q][e] = 0.f;
+            for (int e = 0; e < 4; ++e) { yb[q][e] = 0.f; sb[q][e] = -INFINITY; }
         }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) load_b1(wbase, 0, 0, m);
+        for (int m = 0; m < 8; ++m) load_b1(0, m);
 #pragma unroll 1
         for (int r = 0; r < R; ++r) {
             floatx4 acc[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc[m] = (floatx4){0.f, 0.f, 0.f, 0.f};
             const bool more = r + 1 < R;
-            const float* wrow = wbase;
-            asm volatile("" : "+s"(wrow));               // keep the fragment loads inside the row loop
             const float* xs0 = lds + r * wext + p.half_src[0] * 4 * comp_stride;
             const float* xs1 = lds + r * wext + p.half_src[1] * 4 * comp_stride;
             read_raw(xs0, 0);
@@ -764,8 +773,8 @@ __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, co
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gm[gst][m], (g & 1) ? bfr[m].y : bfr[m].x, acc[m], 0, 0, 0);
                     if (pair_ends) {
                         const int pn = pc + 1;
-                        if (pn < NPCT) load_b1(wrow, pn / NPAIR, pn % NPAIR, m);
-                        else if (more) load_b1(wrow, 0, 0, m);
+                        if (pn < NPCT) load_b1(pn, m);
+                        else if (more) load_b1(0, m);
                     }
                 }
                 if (!last) xforms(raw, gm[gst ^ 1]);
@@ -786,18 +795,20 @@ __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, co
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int chn = chb + q * p.OB;
-                    const float bq = bias ? bias[chn] : 0.f;
-                    const float o[4] = {c[q][0] + bq, c[q][1] + bq, c[q][2] + bq, c[q][3] + bq};
+                    float o[4] = {c[q][0], c[q][1], c[q][2], c[q][3]};
+                    if (bias) { o[0] += bq[q]; o[1] += bq[q]; o[2] += bq[q]; o[3] += bq[q]; }
                     *reinterpret_cast<float4*>(dst + img_off + (unsigned)chn * S + pos_off) = make_float4(o[0], o[1], o[2], o[3]);
                     s1[q] += (o[0] + o[1]) + (o[2] + o[3]);
                     s2[q] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const bool take = r == 0 || sg[q] * o[e] > sg[q] * yb[q][e] || o[e] != o[e];
-                        if (take) {
-                            yb[q][e] = o[e];
-                            bi[q] = (bi[q] & ~(0xFFu << (8 * e))) | ((unsigned)r << (8 * e));
-                        }
+                        // first maximum wins, NaN propagates: "not (key <= best)" is true for a larger key and for NaN, and
+                        // for row 0 (best = -inf); gamma == 0 makes every key 0, so row 0 stays
+                        const float so = sg[q] * o[e];
+                        const bool take = !(so <= sb[q][e]);
+                        yb[q][e] = take ? o[e] : yb[q][e];
+                        sb[q][e] = take ? so : sb[q][e];
+                        bi[q] = take ? ((bi[q] & ~(0xFFu << (8 * e))) | ((unsigned)r << (8 * e))) : bi[q];
                     }
                 }
             }
@@ -1296,7 +1307,9 @@ extern "C" int seld_hcq_first_pool(const seld_conv_desc* d, const float* x, cons
     pl.kp.dst[0] = y; pl.kp.bias[0] = bias; pl.kp.epilogue[0] = want_stats ? SELD_EPI_STATS : 0; pl.kp.stats[0] = stats;
     const HcqPoolP pp{gamma, pool_raw, idx};
     const int NT = pl.NT1 + pl.NT2;
-    const size_t smem = ((size_t)pl.kp.A * pl.IBC * 10 * 72 + (size_t)NT * 4 * 4 * 16 * 2) * sizeof(float);
+    const int npair = ((pl.IBC * 9 + 3) / 4 + 1) / 2;
+    const size_t smem = ((size_t)pl.kp.A * pl.IBC * 10 * 72 + (size_t)NT * 4 * 4 * 16 * 2 +
+                         (size_t)pl.NR * npair * 8 * 64 * 2) * sizeof(float);    // rows + statistics + one tile's fragments
     hipStream_t st = (hipStream_t)stream;
 #define SELD_FP(IBC_, NT1_, NT2_, NR_)                                                                                  \
     do {                                                                                                                \
