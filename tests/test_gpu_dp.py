@@ -173,7 +173,9 @@ def test_graphed_step_matches_eager_step():
             assert int(sdg[k]) == int(sde[k]) == (0 if "batch_gate1" in k else 5), k     # batch_gate1 is never used (model.py:90)
         elif "running_" in k:
             # (small entries of a running mean move by the same absolute amount as large ones between the two trajectories)
-            assert torch.allclose(sdg[k], sde[k], rtol=5e-3, atol=3e-3 * float(sde[k].abs().max()) + 1e-5), k
+            # 3 % of the tensor's scale (the two trajectories part by ~1 % in the deeper blocks): a replay that skipped ONE
+            # of the five updates would be off by ~17 % (momentum 0.1: 1 - 0.9^4 against 1 - 0.9^5)
+            assert torch.allclose(sdg[k], sde[k], rtol=5e-3, atol=3e-2 * float(sde[k].abs().max()) + 1e-5), k
 
 
 def test_graphed_step_draws_fresh_dropout_masks():
