@@ -334,6 +334,10 @@ size_t seld_hcq_pack_entry_bytes(void);
 int seld_hcq_pack_entry(const seld_conv_desc* desc, int32_t mode, int32_t npair, const float* const wA[8],
                         const float* const wB[8], float* wpack, void* entry_host);
 int seld_hcq_pack_table(const void* table_dev, int32_t nentries, int64_t max_floats, void* stream);
+/* the same, balanced over the entries: starts_dev[e] = first 256-float block of entry e (prefix sums of
+ * ceil(floats_e / 256)), starts_dev[nentries] = total_blocks */
+int seld_hcq_pack_flat(const void* table_dev, const int32_t* starts_dev, int32_t nentries, int32_t total_blocks,
+                       void* stream);
 
 /* Weight gradient on the fast product (csrc/hcq_wgrad.hip): dW = sum over positions of dy (x) conj(x) is again a Hamilton
  * product per (output block channel, input block channel, tap): 8 (24 for the dual quaternion) real sub-products

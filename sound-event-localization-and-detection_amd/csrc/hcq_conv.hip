@@ -888,24 +888,27 @@ struct HcqPackP {
 };
 
 __device__ __forceinline__ float hcq_pack_value(const HcqPackP& p, long long idx) {
+    // 32-bit index arithmetic (the host keeps every buffer below 2^31 floats): the 64-bit divisions this decode started
+    // with were most of the kernel's 60 us
     const int NT = p.NT1 + p.NT2;
-    const int set = (int)(idx / p.set_stride);
-    long long r0 = idx - (long long)set * p.set_stride;
-    const int ytile = (int)(r0 / p.ytile_stride);
-    r0 -= (long long)ytile * p.ytile_stride;
+    const unsigned set_stride = (unsigned)p.set_stride, ytile_stride = (unsigned)p.ytile_stride;
+    const unsigned set = (unsigned)idx / set_stride;
+    unsigned r0 = (unsigned)idx - set * set_stride;
+    const int ytile = (int)(r0 / ytile_stride);
+    r0 -= (unsigned)ytile * ytile_stride;
     const bool mix = p.has_mix && ytile == p.nreg;          // the mixed channel tile: same layout, other descriptors
-    const long long rs[2] = {p.range_stride[0], p.range_stride[1]};
-    const long long chunk_stride = rs[0] + (p.NR > 1 ? rs[1] : 0);
+    const unsigned rs[2] = {(unsigned)p.range_stride[0], (unsigned)p.range_stride[1]};
+    const unsigned chunk_stride = rs[0] + (p.NR > 1 ? rs[1] : 0);
     const int chs = (int)(r0 / chunk_stride);            // chunk over all sources
-    r0 -= (long long)chs * chunk_stride;
+    r0 -= (unsigned)chs * chunk_stride;
     const int srcsel = chs / p.nch, ch = chs - srcsel * p.nch;
     const int range = (r0 >= rs[0]) ? 1 : 0;
     if (range) r0 -= rs[0];
     const int ntr = range ? p.NT2 : NT;
     const int per_m = 64 * 2 * ntr;
     const int per_pair = 8 * per_m;
-    const int j = (int)(r0 / per_pair);
-    int r1 = (int)(r0 - (long long)j * per_pair);
+    const int j = (int)(r0 / (unsigned)per_pair);
+    int r1 = (int)(r0 - (unsigned)j * (unsigned)per_pair);
     const int m = r1 / per_m;
     r1 -= m * per_m;
     const int lane = r1 / (2 * ntr);
@@ -960,8 +963,23 @@ __global__ __launch_bounds__(256) void hcq_pack_kernel(const HcqPackP p) {
     if (idx < p.total) p.out[idx] = hcq_pack_value(p, idx);
 }
 
-// Every registered layer in ONE launch (once per optimiser step): blockIdx.y = table entry, blockIdx.x = 256-float
-// block of that entry's buffer.
+// Every registered layer in ONE launch (once per optimiser step), balanced: blockIdx.x runs over the 256-float blocks of
+// ALL entries back to back; starts[e] = first block of entry e (starts[nentries] = total).  (A (blocks, entries) grid sized
+// for the largest entry launched mostly empty workgroups, a capped one looped: 60 us either way.)
+__global__ __launch_bounds__(256) void hcq_pack_flat_kernel(const HcqPackP* __restrict__ table, const int* __restrict__ starts,
+                                                            int nentries) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = nentries;                       // last entry with starts[e] <= b
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (starts[mid] <= b) lo = mid; else hi = mid;
+    }
+    const HcqPackP& p = table[lo];
+    const long long idx = (long long)(b - starts[lo]) * 256 + threadIdx.x;
+    if (idx < p.total) p.out[idx] = hcq_pack_value(p, idx);
+}
+
+// (the (blocks, entries) form: blockIdx.y = table entry, blockIdx.x = 256-float block of that entry's buffer)
 __global__ __launch_bounds__(256) void hcq_pack_table_kernel(const HcqPackP* __restrict__ table, int nentries) {
     const int e = blockIdx.y;
     if (e >= nentries) return;
@@ -1261,6 +1279,15 @@ extern "C" int seld_hcq_pack_table(const void* table_dev, int32_t nentries, int6
     if (bx > 512) bx = 512;
     hipLaunchKernelGGL(hcq_pack_table_kernel, dim3((unsigned)bx, (unsigned)nentries), dim3(256), 0, (hipStream_t)stream,
                        (const HcqPackP*)table_dev, nentries);
+    return check_launch();
+}
+
+/* The balanced form: starts_dev[e] = first 256-float block of entry e, starts_dev[nentries] = total_blocks. */
+extern "C" int seld_hcq_pack_flat(const void* table_dev, const int32_t* starts_dev, int32_t nentries, int32_t total_blocks,
+                                  void* stream) {
+    if (!table_dev || !starts_dev || nentries <= 0 || total_blocks <= 0) return SELD_EINVAL;
+    hipLaunchKernelGGL(hcq_pack_flat_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const HcqPackP*)table_dev, starts_dev, nentries);
     return check_launch();
 }
 

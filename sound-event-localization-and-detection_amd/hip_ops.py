@@ -530,10 +530,13 @@ class _HcqWeights:
             import numpy as np
             raw = b"".join(e.host for e in live)
             self.table = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(live[0].buf.device)
-            self.max_floats = max(e.buf.numel() for e in live)
+            starts = np.zeros(len(live) + 1, dtype=np.int32)
+            starts[1:] = np.cumsum([(e.buf.numel() + 255) // 256 for e in live])
+            self.starts = torch.from_numpy(starts).to(live[0].buf.device)
+            self.total_blocks = int(starts[-1])
             self.table_dirty = False
-        L.check(L.lib().seld_hcq_pack_table(L.ptr(self.table), len(live), ctypes.c_int64(self.max_floats),
-                                            L.current_stream()), "seld_hcq_pack_table")
+        L.check(L.lib().seld_hcq_pack_flat(L.ptr(self.table), L.ptr(self.starts), len(live), self.total_blocks,
+                                           L.current_stream()), "seld_hcq_pack_flat")
         for e in live:
             e.epoch, e.vers = self.epoch, None
         self.packed_epoch = self.epoch
