@@ -13,9 +13,12 @@ no host time between them.  HIP events cannot bracket a kernel inside a replayed
 roofline figures come from an instrumented EAGER pass of the same step run right after the timed region, in
 this process, on the stream the kernels are launched on (`roofline.measured_over` says so).
 
-For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: one process
-per GPU, two RCCL all-reduces of the flat gradient buffer per step (dp.BucketedGradSync), weak scaling
-(per-GPU batch fixed: the workload's own per-GPU batch, e.g. 16 for the 4- and 8-GPU configs c4 / c5).
+N > 1: one process per GPU, two RCCL all-reduces of the flat gradient buffer per step (dp.BucketedGradSync), weak
+scaling (per-GPU batch fixed: the workload's own per-GPU batch, e.g. 16 for the 4- and 8-GPU configs c4 / c5).
+Either launch it under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the ranks find
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or plainly as `python bench.py --gpus N`: the process
+then is a PARENT that never touches the GPU -- it starts that same torch.distributed.run command as a child on a free
+port of 127.0.0.1, relays rank 0's JSON line and exits with the child's code.
 """
 import argparse
 import importlib
@@ -152,6 +155,35 @@ def cpu_baseline(w, freq=128, seconds_budget=14.0):
                        f"(oracle, torch-CPU fp32, dropout on); `runs` lists every thread setting, `value` is the faster")
 
 
+def launch_ranks(argv, n):
+    """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks as children of THIS process
+    (which has not touched the GPU and never will: no exec, no HIP call), relay rank 0's JSON line, return the exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SELD_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:                    # rank 0 prints the one JSON line; anything else on stdout goes to stderr
+        txt = out.strip()
+        if line is None and txt.startswith("{") and '"metric"' in txt:
+            line = txt
+        elif txt:
+            print(txt, file=sys.stderr)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +201,10 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if os.environ.get("SELD_BENCH_CHILD"):
+            raise SystemExit("bench.py: rank process without WORLD_SIZE in its environment")
+        raise SystemExit(launch_ranks(sys.argv[1:], args.gpus))          # before anything touches the GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     pkg = importlib.import_module(PKG)
@@ -308,6 +344,9 @@ def main():
                                    f"batch {batch}/GPU, random-init weights", "global_batch": batch * world,
                        "parallelism": f"dp{world}", "step_mode": step_mode},
             "loss": round(final_loss, 6),
+            # world size as torch.distributed sees it after init (1 = no process group) and the backend that carried it
+            "rccl_ranks": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
+            "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
         }
         if summ:
             def rates(label, d, nsteps):

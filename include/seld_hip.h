@@ -428,12 +428,13 @@ int seld_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_a
  * replayed: 4 x uint64 = { Philox base added to every dropout offset, optimiser step (1-based), learning rate (float
  * bits in the low word), Philox draws per step }.
  * seld_step_begin replaces `optimizer.zero_grad()` (train.py:552): zeroes the flat gradient buffer (n floats, 16-byte
- * aligned) and, if state is non-null, advances state[0] += state[3], state[1] += 1.
- * seld_adam_flat_state is seld_adam_flat with step = state[1] and lr = state[2]. */
+ * aligned) and, if state is non-null, advances state[1] += 1.
+ * seld_adam_flat_state is seld_adam_flat with step = state[1] and lr = state[2]; as the last launch of a step it also
+ * moves the Philox base past the step's draws, state[0] += state[3]. */
 int seld_step_begin(float* flat_grad, int64_t n, uint64_t* state, void* stream);
 int seld_adam_flat_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                          float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                         const uint64_t* state, void* stream);
+                         uint64_t* state, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * STFT magnitude / phase (utility_functions.py:129-155 = scipy.signal.stft(window='hamming',

@@ -808,7 +808,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 __global__ __launch_bounds__(256) void adam_state_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, long long n,
                                                          float b1, float b2, float eps, float wd, float gscale,
-                                                         const uint64_t* __restrict__ state) {
+                                                         uint64_t* __restrict__ state) {
+    // end of the step: the Philox base moves past this step's draws (nothing after Adam draws), so whatever is issued
+    // next -- a replay or an eager launch with host offsets from 0 -- sees fresh counters
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[0] += state[3];
     const float step = (float)state[1];
     const float lr = __uint_as_float((unsigned)state[2]);
     const float bc1 = 1.0f - powf(b1, step);
@@ -826,14 +829,11 @@ __global__ __launch_bounds__(256) void adam_state_kernel(float* __restrict__ p, 
     }
 }
 
-// Start of a training step: zero the flat gradient buffer (16-byte stores) and advance the step state
-//   state[0] += state[3]   Philox base (state[3] = draws per step, set by the host once it is known)
-//   state[1] += 1          optimiser step
+// Start of a training step: zero the flat gradient buffer (16-byte stores) and advance the optimiser step
+//   state[1] += 1
+// (the Philox base state[0] advances by state[3] = draws per step at the END of the step, in adam_state_kernel)
 __global__ __launch_bounds__(256) void step_begin_kernel(float* __restrict__ g, long long n, uint64_t* __restrict__ state) {
-    if (state && blockIdx.x == 0 && threadIdx.x == 0) {
-        state[0] += state[3];
-        state[1] += 1;
-    }
+    if (state && blockIdx.x == 0 && threadIdx.x == 0) state[1] += 1;
     const long long n4 = n >> 2;
     float4* g4 = reinterpret_cast<float4*>(g);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
@@ -1137,7 +1137,7 @@ extern "C" int seld_adam_flat(float* param, const float* grad, float* exp_avg, f
 }
 extern "C" int seld_adam_flat_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                     float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                                    const uint64_t* state, void* stream) {
+                                    uint64_t* state, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !state || n < 0) return SELD_EINVAL;
     if (n == 0) return SELD_OK;
     hipLaunchKernelGGL(adam_state_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq,

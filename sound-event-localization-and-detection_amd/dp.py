@@ -107,6 +107,11 @@ def cut_backward_here(module, x):
     cuts = getattr(module, "_backward_cuts", None)
     if cuts is None or not x.requires_grad:
         return x
+    if any(leaf.grad is not None for _, leaf in cuts):
+        # a backward pass ran to the cut and nobody ran the rest: the front end would silently get no gradient
+        raise RuntimeError("BackwardCut: the previous step's backward pass stopped at the front-end cut and finish() was "
+                           "never called (use dp.dp_train_step / GraphedTrainStep, or remove() the cut before a plain "
+                           "loss.backward())")
     leaf = x.detach().requires_grad_(True)
     cuts.append((x, leaf))
     return leaf
@@ -137,6 +142,19 @@ class BackwardCut:
         for b in self.blocks:
             if getattr(b, "_backward_cuts", None) is self.cuts:
                 del b._backward_cuts
+
+    def install(self):
+        for b in self.blocks:
+            b._backward_cuts = self.cuts
+
+    def __enter__(self):
+        self.install()
+        self.reset()
+        return self
+
+    def __exit__(self, *exc):
+        self.remove()
+        return False
 
 
 class BucketedGradSync:
@@ -197,6 +215,8 @@ def broadcast_parameters(module_or_flat, src=0):
         return
     for t in list(module_or_flat.parameters()) + list(module_or_flat.buffers()):
         dist.broadcast(t.data, src)
+    from . import hip_ops as H              # written through .data: no version counter moved
+    H.hcq_weights.weights_changed()
 
 
 def average_bn_running_stats(module):

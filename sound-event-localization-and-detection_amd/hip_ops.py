@@ -511,14 +511,17 @@ class _HcqWeights:
 
     def _pack_all(self):
         dead = []
+        versions = {}
         for key, e in self.entries.items():
             if e is None:
                 continue
             ws = self._alive(e)
             if ws is None or any(not w.is_cuda for w in ws):
                 dead.append(key)
-            elif tuple(w.data_ptr() for w in ws) != e.ptrs:
+                continue
+            if tuple(w.data_ptr() for w in ws) != e.ptrs:
                 self._fill(e, ws)
+            versions[id(e)] = tuple(w._version for w in ws)
         for key in dead:
             del self.entries[key]
             self.table_dirty = True
@@ -537,9 +540,20 @@ class _HcqWeights:
             self.table_dirty = False
         L.check(L.lib().seld_hcq_pack_flat(L.ptr(self.table), L.ptr(self.starts), len(live), self.total_blocks,
                                            L.current_stream()), "seld_hcq_pack_flat")
+        # the version counters the forms were built from: an in-place edit torch knows about (load_state_dict) between now
+        # and the entry's next request shows as a mismatch there and re-packs that entry (with None recorded
+        # here, an entry that was bulk-packed and then edited was served stale)
         for e in live:
-            e.epoch, e.vers = self.epoch, None
+            e.epoch, e.vers = self.epoch, versions[id(e)]
         self.packed_epoch = self.epoch
+
+    def pin_for_graph(self):
+        """Everything a RECORDED seld_hcq_pack_flat launch points at: the table, the block starts and the entries' form
+        buffers as they are now.  `_pack_all` never edits a table in place -- it builds new tensors when an entry is added
+        -- so a recorded step that holds these references keeps replaying against valid memory whatever shapes are
+        registered later (validation at another batch size, an eval-only pooling entry)."""
+        live = [e for e in self.entries.values() if e is not None]
+        return (self.table, getattr(self, "starts", None), [e.buf for e in live])
 
     def get(self, desc, mode, wsA, wsB=None):
         """Packed forms for (desc, mode) of the given component tensors, or None if the shape runs on the 16/48-product

@@ -112,7 +112,8 @@ class FlatAdam:
 
     def step(self, grad_scale=1.0, state=None):
         """`state`: take the step number and the learning rate from the device-resident step state instead of the
-        host's (graph-recorded steps; `sync_from_state` brings the host's count up to date afterwards)."""
+        host's (graph-recorded steps; GraphedTrainStep keeps the host's count in step and `sync_from_host` pushes host-side
+        changes -- eager steps, a restored optimiser -- back into the state before the next replay)."""
         H.join_side_stream()            # weight gradients issued on the side stream (hip_ops._on_side_stream)
         H.hcq_weights.weights_changed() # the packed weight forms of the fast-product convolutions are stale now
         g = self.param_groups[0]
@@ -144,6 +145,7 @@ class FlatAdam:
 
     def load_state_dict(self, sd):
         """Accepts torch.optim.Adam's layout (reference checkpoints) and this class's round-1 flat layout."""
+        H.hcq_weights.weights_changed()      # a restore usually comes with new weights: never serve forms from before it
         if "exp_avg" in sd:                                   # flat layout
             self.step_count = int(sd["step"])
             self.exp_avg.copy_(sd["exp_avg"])
@@ -235,6 +237,10 @@ class GraphedTrainStep:
         self.state[3] = H.philox.offset
         H.philox.offset = 0
         self.replays = 0
+        self._step_seen = self.opt.step_count
+        # the recorded weight-form launch reads the cache's table / block starts / form buffers through raw pointers:
+        # hold them, the cache builds NEW tensors when a shape is registered later (hip_ops._HcqWeights.pin_for_graph)
+        self._hcq_pinned = H.hcq_weights.pin_for_graph()
 
     def _push_lr(self):
         lr = float(self.opt.param_groups[0]["lr"])
@@ -283,6 +289,7 @@ class GraphedTrainStep:
         if target is not None:
             self.target.copy_(target, non_blocking=True)
         self._push_lr()
+        self.sync_from_host()
         self.graphs[0].replay()
         if self.cut is not None:
             self.sync.reduce_main()
@@ -292,7 +299,22 @@ class GraphedTrainStep:
             self.graphs[2].replay()
         self.replays += 1
         self.opt.step_count += 1
+        self._step_seen = self.opt.step_count
+        # the replayed Adam step rewrote the weights behind the host cache's back: an eager forward after this (validation,
+        # an instrumented step) must re-pack the fast-product weight forms
+        H.hcq_weights.weights_changed()
         return self.loss
+
+    def sync_from_host(self):
+        """Bring the device-resident step state up to date with what happened on the host between replays: eager steps
+        or `optimizer.load_state_dict` moved the step count; eager dropout draws moved the host Philox offset (a replay's
+        own draws are recorded with offsets from 0 on top of the device base, which the step itself advances)."""
+        if self.opt.step_count != self._step_seen:
+            self.state[1] = self.opt.step_count
+            self._step_seen = self.opt.step_count
+        if H.philox.offset:
+            self.state[0] += int(H.philox.offset)
+            H.philox.offset = 0
 
 
 _ADAM_DEFAULTS = None
@@ -447,6 +469,7 @@ def load_model(model, optimizer, path, cuda, device, scheduler=None):
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in ck['model_state_dict'].items()}
     target = model.module if hasattr(model, "module") else model
     target.load_state_dict(sd)
+    H.hcq_weights.weights_changed()          # the packed weight forms of the fast-product convolutions are stale now
     if optimizer is not None:
         optimizer.load_state_dict(ck['optimizer_state_dict'])
     if scheduler is not None:

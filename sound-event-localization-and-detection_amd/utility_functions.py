@@ -34,11 +34,34 @@ def spectrum_fast(x, nperseg=512, noverlap=128, window='hamming', cut_dc=True, o
     scipy.signal.stft(x, window, nperseg, noverlap) -> |Z| [-> concatenated with angle(Z) on the channel axis]
     [-> DC bin dropped] [-> last frame dropped].
 
-    x: (channels, samples).  A numpy array gives a float64 numpy array like the reference (the transform itself is
-    computed in float32 on the device); a torch tensor gives a float32 tensor on the GPU.
+    x: (channels, samples).  A numpy array gives a numpy array of the reference's dtype -- float32 for float32 input
+    (scipy's stft returns complex64 then), float64 for anything else; the transform itself is computed in float32 on
+    the device -- and a torch tensor gives a float32 tensor on the GPU.
     Returns (channels or 2*channels, nperseg/2 + 1 - cut_dc, frames - cut_last_timeframe).
+
+    Batched input (..., channels, samples) follows the reference literally: the transform runs over the last axis, phase
+    is concatenated on axis -3, and the two cuts are the reference's `output[:, 1:, :]` / `output[:, :, :-1]` -- which on
+    a batched array act on axes 1 and 2 (channels and frequency), not on the DC bin and the last frame.
     '''
     is_numpy = not torch.is_tensor(x)
+    if is_numpy:
+        x = np.asarray(x)
+        out_dtype = np.float32 if x.dtype == np.float32 else np.float64
+    if (x.ndim if is_numpy else x.dim()) > 2:
+        lead, C = tuple(x.shape[:-2]), x.shape[-2]
+        flat = x.reshape((-1, x.shape[-1]))
+        if is_numpy:
+            flat = torch.as_tensor(np.ascontiguousarray(flat, dtype=np.float32))
+        rows = flat.shape[0]
+        both = spectrum_fast(flat, nperseg, noverlap, window, False, output_phase, False)   # [|Z| rows ; angle rows]
+        output = both[:rows].reshape(lead + (C,) + tuple(both.shape[1:]))
+        if output_phase:
+            output = torch.cat((output, both[rows:].reshape(output.shape)), dim=-3)
+        if cut_dc:
+            output = output[:, 1:, :]
+        if cut_last_timeframe:
+            output = output[:, :, :-1]
+        return output.cpu().numpy().astype(out_dtype) if is_numpy else output
     t = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if is_numpy else x
     if t.dim() != 2:
         raise ValueError(f"spectrum_fast expects (channels, samples), got shape {tuple(t.shape)}")
@@ -62,5 +85,5 @@ def spectrum_fast(x, nperseg=512, noverlap=128, window='hamming', cut_dc=True, o
                                           int(bool(cut_last_timeframe)), L.ptr(win), L.ptr(out), L.current_stream()),
                 "seld_stft_magphase_ex")
     if is_numpy:
-        return out.cpu().numpy().astype(np.float64)
+        return out.cpu().numpy().astype(out_dtype)
     return out

@@ -363,7 +363,21 @@ def test_spectrum_fast_drop_in_matches_reference(golden):
     n = np.arange(6400)
     x = np.stack([np.sin(2 * np.pi * (100 + 37 * c) * n / 32000) + 0.1 * np.sin(0.013 * n * (c + 1)) for c in range(8)])
     out = UF.spectrum_fast(x, nperseg=512, noverlap=112)
-    assert isinstance(out, np.ndarray) and out.dtype == np.float64           # numpy in -> float64 numpy out
+    assert isinstance(out, np.ndarray) and out.dtype == np.float64 == np.dtype(str(g["dtype_f64"]))   # float64 in -> float64 out
+    # float32 in -> float32 out, as scipy's stft gives the reference (the usual case: librosa loads float32)
+    out32 = UF.spectrum_fast(x.astype(np.float32), nperseg=512, noverlap=112)
+    assert out32.dtype == np.float32 == np.dtype(str(g["dtype_f32"]))
+    _check_spectrum(out32.astype(np.float64), g["magphase_112_f32"].astype(np.float64), 8, True, "float32 input")
+    # batched (2, 3, samples): the reference's axis handling, literally (phase on axis -3, cuts on axes 1 and 2)
+    xb = np.stack((x[:3], x[3:6]))
+    ob = UF.spectrum_fast(xb, nperseg=512, noverlap=112)
+    rb = g["batched_112"]
+    assert ob.shape == rb.shape == (2, 5, 256, 17)
+    for n_ in range(2):        # planes 0-1 are magnitudes of channels 1-2, planes 2-4 the three phases
+        _check_spectrum(np.concatenate((ob[n_, :2], ob[n_, 3:5])), np.concatenate((rb[n_, :2], rb[n_, 3:5])), 2, True, "batched")
+    om = UF.spectrum_fast(xb, nperseg=512, noverlap=112, cut_dc=False, output_phase=False)
+    assert om.shape == g["batched_mag_nodc"].shape
+    _check_spectrum(om.reshape(6, 256, 17), g["batched_mag_nodc"].reshape(6, 256, 17), 6, False, "batched magnitude")
     _check_spectrum(out, g["magphase_112"], 8, True, "defaults, noverlap 112")
     _check_spectrum(UF.spectrum_fast(x, 512, 112, output_phase=False), g["mag_112"], 8, False, "magnitude only")
     _check_spectrum(UF.spectrum_fast(x, 512, 128), g["magphase_128"], 8, True, "noverlap 128")
