@@ -359,6 +359,25 @@ int seld_hcq_wgrad_row_label(const seld_conv_desc* desc, int32_t npair, char* bu
 int seld_hcq_wgrad_row_acc(const seld_conv_desc* desc, int32_t npair, const float* x, const float* dyA, const float* dyB,
                            float* const dwA[8], float* const dwB[8], void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight gradients of a LIST of dual-quaternion convolutions in one grouped, persistent launch per shape family
+ * (csrc/hcq_wgrad_grp.hip): dw[c] += d loss / d W_c for every job, i.e. dual_quaternion_conv
+ * (dual_quaternion/dual_quaternion_ops.py:111-153) differentiated w.r.t. its eight component weights, which the reference
+ * leaves to autograd through F.convNd (dual_quaternion_ops.py:153).  24 block products per layer; no atomics and a fixed
+ * summation order: the result is reproducible from run to run.  x / dy: input and output-gradient tensors of the layer
+ * (contiguous NCHW / NCT, desc.N images); dw: the eight component gradient tensors (Cout/8, Cin/8, kh, kw), accumulated into.
+ * Shapes taken: algebra 8, 'same' stride-1 layers with rows of >= 128 positions (a multiple of 16) and
+ * (Cout/8, Cin/8, kernel) = (48, 24, 1x3), (24, 48, 1x1), (24, 24, 3x3), (48, 48, 1x3); all jobs of one family share N and
+ * the row length.  seld_hcq_wgrad_group_workspace returns the scratch bytes (0: a job is not taken -- use the per-layer entry
+ * points); the scratch needs no initialisation. */
+typedef struct seld_wgrad_job {
+    seld_conv_desc desc;
+    const float* x;
+    const float* dy;
+    float* dw[8];
+} seld_wgrad_job;
+size_t seld_hcq_wgrad_group_workspace(const seld_wgrad_job* jobs, int32_t njobs);
+int seld_hcq_wgrad_group(const seld_wgrad_job* jobs, int32_t njobs, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Elementwise / pooling / dropout   (torch.nn.ReLU/Tanh/MaxPool/Dropout at model.py:175-202,
  * 280-282, 449-451)

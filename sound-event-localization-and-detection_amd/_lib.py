@@ -28,6 +28,11 @@ class ConvDesc(ctypes.Structure):
                 ("dil", ctypes.c_int32 * 2), ("groups", ctypes.c_int32)]
 
 
+class WgradJob(ctypes.Structure):
+    """seld_wgrad_job (include/seld_hip.h): one convolution of a grouped weight-gradient call."""
+    _fields_ = [("desc", ConvDesc), ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p * 8)]
+
+
 _lib = None
 
 
@@ -42,6 +47,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.seld_build_arch.restype = ctypes.c_char_p
         _lib.seld_hc_conv_bwd_weight_workspace.restype = ctypes.c_size_t
+        _lib.seld_hcq_wgrad_group_workspace.restype = ctypes.c_size_t
     return _lib
 
 

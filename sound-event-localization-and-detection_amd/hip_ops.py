@@ -268,6 +268,44 @@ def hcq_wgrad_acc(desc, x, dyA, dwA, dyB=None, dwB=None):
                 "seld_hcq_wgrad_acc")
 
 
+# ---- grouped weight gradients (csrc/hcq_wgrad_grp.hip) -----------------------------------------------------------------
+_wgrad_group_scratch = {}
+
+
+def wgrad_group_jobs(jobs):
+    """ctypes array of seld_wgrad_job from [(desc, x, dy, [8 gradient tensors]), ...]."""
+    arr = (L.WgradJob * len(jobs))()
+    for a, (desc, x, dy, dws) in zip(arr, jobs):
+        ctypes.memmove(ctypes.byref(a.desc), ctypes.byref(desc), ctypes.sizeof(L.ConvDesc))
+        a.x, a.dy = x.data_ptr(), dy.data_ptr()
+        for i in range(8):
+            a.dw[i] = dws[i].data_ptr()
+    return arr
+
+
+def wgrad_group_bytes(jobs_arr):
+    """Scratch bytes of a grouped call, 0 when one of the jobs is not a shape the grouped kernels take."""
+    return int(L.lib().seld_hcq_wgrad_group_workspace(jobs_arr, len(jobs_arr)))
+
+
+def wgrad_group(jobs):
+    """dw[c] += weight gradient for every (desc, x, dy, dws) of `jobs` -- dual-quaternion convolutions of the shape
+    families of seld_hcq_wgrad_group -- in one persistent launch per family.  Returns False (nothing launched) when a job
+    is not taken.  Deterministic: no atomics, fixed summation order."""
+    arr = wgrad_group_jobs(jobs)
+    nbytes = wgrad_group_bytes(arr)
+    if nbytes == 0:
+        return False
+    dev = jobs[0][1].device
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _wgrad_group_scratch.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _wgrad_group_scratch[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    L.check(L.lib().seld_hcq_wgrad_group(arr, len(arr), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.current_stream()),
+            "seld_hcq_wgrad_group")
+    return True
+
+
 def conv_bwd_weight(desc, x, dy, w_shape, want_bias, into=None, bias_into=None):
     """Component weight gradients.  `into` (list of A tensors, e.g. views of FlatAdam.flat_grad) selects the
     accumulating entry point: the kernel adds straight into them and nothing is returned for autograd."""
@@ -509,7 +547,13 @@ class _HcqWeights:
         e.epoch = -1
         self.table_dirty = True
 
-    def _pack_all(self):
+    def refresh_table(self):
+        """Bring the device-side table up to date with the registered entries WITHOUT packing (host work + two small
+        host-to-device copies).  train.GraphedTrainStep calls it right before recording: entries registered during the
+        warm-up step left the table dirty, and the copies are not allowed inside a stream capture."""
+        return self._collect()[0]
+
+    def _collect(self):
         dead = []
         versions = {}
         for key, e in self.entries.items():
@@ -526,10 +570,7 @@ class _HcqWeights:
             del self.entries[key]
             self.table_dirty = True
         live = [e for e in self.entries.values() if e is not None]
-        if not live:
-            self.packed_epoch = self.epoch
-            return
-        if self.table_dirty:
+        if live and self.table_dirty:
             import numpy as np
             raw = b"".join(e.host for e in live)
             self.table = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(live[0].buf.device)
@@ -538,6 +579,13 @@ class _HcqWeights:
             self.starts = torch.from_numpy(starts).to(live[0].buf.device)
             self.total_blocks = int(starts[-1])
             self.table_dirty = False
+        return live, versions
+
+    def _pack_all(self):
+        live, versions = self._collect()
+        if not live:
+            self.packed_epoch = self.epoch
+            return
         L.check(L.lib().seld_hcq_pack_flat(L.ptr(self.table), L.ptr(self.starts), len(live), self.total_blocks,
                                            L.current_stream()), "seld_hcq_pack_flat")
         # the version counters the forms were built from: an in-place edit torch knows about (load_state_dict) between now

@@ -217,6 +217,7 @@ class GraphedTrainStep:
         self.state[3] = 0
         H.philox.offset = 0
         self._push_lr()
+        H.hcq_weights.refresh_table()       # host-to-device copies of the weight-form table: not allowed while capturing
         self.graphs = []
         ga = torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga):

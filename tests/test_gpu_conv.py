@@ -547,3 +547,90 @@ def test_hcq_wgrad_row_matches_block_matrix_kernels(shape, cout, k, pad, dil, se
         (yr * dyB.cpu().double()).sum().backward()
         for a, b in zip(new[2], w64):
             _close(a, b.grad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# grouped persistent weight gradient (csrc/hcq_wgrad_grp.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def _grp_job(H, shape, cout, k, pad, dil, gen, dev):
+    kk = (k,) if isinstance(k, int) else k
+    desc = H.make_conv_desc(tuple(shape), cout, 8, kk, 1, pad, dil)
+    x = torch.randn(shape, generator=gen).to(dev)
+    yshape = (shape[0], cout) + tuple(shape[2:])
+    dy = torch.randn(yshape, generator=gen).to(dev)
+    wshape = (cout // 8, shape[1] // 8) + tuple(kk)
+    return desc, x, dy, wshape
+
+
+GRP_LISTS = {
+    # the residual blocks' dilated pairs (dilations straddling the 16-position step and the 4-column alignment) + tcn.conv1-like
+    "tcn_1x3": [((4, 192, 512), 384, 3, d, d) for d in (1, 2, 3, 5, 8, 13, 21, 34, 55)] + [((4, 192, 512), 384, 3, 1, 1)],
+    # skip / residual 1x1
+    "tcn_1x1": [((4, 384, 512), 192, 1, 0, 1)] * 5,
+    # cnn.1 / cnn.2: three kernel rows each, different heights in one launch
+    "cnn_3x3": [((2, 192, 16, 512), 192, (3, 3), 1, 1), ((2, 192, 2, 512), 192, (3, 3), 1, 1)],
+    # tcn.conv2: 384 -> 384 1x3 as three single-tap sub-jobs
+    "wide_1x3": [((4, 384, 128), 384, 3, 1, 1)],
+    # everything at once: four families in one call, shorter rows
+    "mixed": [((2, 192, 256), 384, 3, 2, 2), ((2, 384, 256), 192, 1, 0, 1), ((2, 384, 256), 384, 3, 1, 1)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(GRP_LISTS))
+def test_wgrad_group_matches_block_matrix_kernels_and_oracle(name, seld_env):
+    """seld_hcq_wgrad_group on a list of layers (one persistent launch per shape family: work split across layer
+    boundaries, sub-jobs per kernel row / tap, combined and split accumulator layouts) against the 48-product per-layer
+    kernels, which the oracle tests pin; the first job of every list also against the fp64 oracle; accumulation into
+    non-zero gradient slots; bit-identical results from two calls (no atomics, fixed summation order)."""
+    import seld_amd
+    H = seld_amd.hip_ops
+    gen = torch.Generator().manual_seed(17)
+    dev = torch.device("cuda:0")
+    specs = GRP_LISTS[name]
+    jobs, refs = [], []
+    for shape, cout, k, pad, dil in specs:
+        desc, x, dy, wshape = _grp_job(H, shape, cout, k, pad, dil, gen, dev)
+        dws = [torch.full(wshape, 0.25 * (c + 1), device=dev) for c in range(8)]           # non-zero slots: the call ADDS
+        jobs.append((desc, x, dy, dws))
+    assert H.wgrad_group(jobs), "a job of the list was not taken by the grouped kernels"
+    torch.cuda.synchronize()
+    first = [[w.clone() for w in j[3]] for j in jobs]
+    seld_env.set("SELD_CONV_NO_HCQ", "1")                 # the 48-product per-layer kernels
+    for (desc, x, dy, dws), got in zip(jobs, first):
+        old = [torch.full_like(w, 0.25 * (c + 1)) for c, w in enumerate(dws)]
+        H.conv_bwd_weight(desc, x, dy, tuple(dws[0].shape), False, into=old)
+        scale = max(float(o.abs().max()) for o in old)
+        for a, b in zip(got, old):
+            assert float((a - b).abs().max()) <= REL * scale, (name, float((a - b).abs().max()), scale)
+    seld_env.unset("SELD_CONV_NO_HCQ")
+    # oracle on the first job
+    desc, x, dy, dws = jobs[0]
+    shape, cout, k, pad, dil = specs[0]
+    kk = (k,) if isinstance(k, int) else k
+    w64 = [torch.zeros(dws[0].shape, dtype=torch.float64, requires_grad=True) for _ in range(8)]
+    yr = O.hypercomplex_conv(x.cpu().double(), w64, None, 1, pad, 1, dil, mode="explicit")
+    (yr * dy.cpu().double()).sum().backward()
+    scale = max(float(w.grad.abs().max()) for w in w64)
+    for c, (a, b) in enumerate(zip(first[0], w64)):
+        assert float((a.cpu().double() - 0.25 * (c + 1) - b.grad).abs().max()) <= REL * scale
+    # second call on fresh slots: bit-identical
+    for j in jobs:
+        for c, w in enumerate(j[3]):
+            w.fill_(0.25 * (c + 1))
+    assert H.wgrad_group(jobs)
+    torch.cuda.synchronize()
+    for j, got in zip(jobs, first):
+        for a, b in zip(j[3], got):
+            assert torch.equal(a, b), name
+
+
+def test_wgrad_group_refuses_other_shapes():
+    import seld_amd
+    H = seld_amd.hip_ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(1)
+    for shape, cout, k, pad, dil in [((2, 16, 64), 32, 3, 1, 1), ((2, 192, 520), 384, 3, 1, 1), ((2, 192, 512), 384, 3, 70, 70)]:
+        desc, x, dy, wshape = _grp_job(H, shape, cout, k, pad, dil, gen, dev)
+        dws = [torch.zeros(wshape, device=dev) for _ in range(8)]
+        assert H.wgrad_group([(desc, x, dy, dws)]) is False
+        assert all(float(w.abs().max()) == 0.0 for w in dws)
