@@ -366,8 +366,8 @@ int seld_hcq_wgrad_row_acc(const seld_conv_desc* desc, int32_t npair, const floa
  * summation order: the result is reproducible from run to run.  x / dy: input and output-gradient tensors of the layer
  * (contiguous NCHW / NCT, desc.N images); dw: the eight component gradient tensors (Cout/8, Cin/8, kh, kw), accumulated into.
  * Shapes taken: algebra 8, 'same' stride-1 layers with rows of >= 128 positions (a multiple of 16) and
- * (Cout/8, Cin/8, kernel) = (48, 24, 1x3), (24, 48, 1x1), (24, 24, 3x3), (48, 48, 1x3); all jobs of one family share N and
- * the row length.  seld_hcq_wgrad_group_workspace returns the scratch bytes (0: a job is not taken -- use the per-layer entry
+ * (Cout/8, Cin/8, kernel) = (48, 24, 1x3), (24, 48, 1x1), (24, 24, 3x3), (48, 48, 1x3): families 0..3, one persistent launch
+ * per family present in the list.  seld_hcq_wgrad_group_workspace returns the scratch bytes (0: a job is not taken -- use the per-layer entry
  * points); the scratch needs no initialisation. */
 typedef struct seld_wgrad_job {
     seld_conv_desc desc;
@@ -375,6 +375,7 @@ typedef struct seld_wgrad_job {
     const float* dy;
     float* dw[8];
 } seld_wgrad_job;
+int seld_hcq_wgrad_group_family(const seld_conv_desc* desc);      /* 0..3 as listed above, -1 = not taken */
 size_t seld_hcq_wgrad_group_workspace(const seld_wgrad_job* jobs, int32_t njobs);
 int seld_hcq_wgrad_group(const seld_wgrad_job* jobs, int32_t njobs, void* workspace, size_t workspace_bytes, void* stream);
 

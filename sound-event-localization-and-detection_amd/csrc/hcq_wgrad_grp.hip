@@ -49,13 +49,13 @@ struct GwJob {
     int woff0, wstep;      // input column of tap t = output column + woff0 + t * wstep
     int hoff;              // input row = output row + hoff
     int step0;             // first step of this job in the launch's concatenated step space
-    int pad_;
+    int W;                 // row length (a multiple of 16)
 };
 
 struct GwP {
     GwJob job[GW_MAXJ];
     float* part;           // [nwg + njobs][8 forms][NT tiles][256]
-    int njobs, N, W, per;  // per = steps per workgroup
+    int njobs, per;        // per = steps per workgroup
     int total;             // all steps
 };
 
@@ -158,7 +158,6 @@ __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
     int g1 = g0 + p.per;
     if (g1 > p.total) g1 = p.total;
     if (g0 >= g1) return;
-    const int spr = p.W >> 4;                              // steps per row
     int jb = 0;
     while (jb + 1 < p.njobs && p.job[jb + 1].step0 <= g0) ++jb;
 
@@ -191,9 +190,10 @@ __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
         const int jend = (jb + 1 < p.njobs) ? p.job[jb + 1].step0 : p.total;
         const int s_end = (g1 < jend ? g1 : jend) - J.step0;          // steps of this job are [s_beg, s_end)
         const int s_beg = g - J.step0;
-        const int H = J.H;
-        const long long dy_img = (long long)(8 * OA) * H * p.W, x_img = (long long)(8 * IB) * H * p.W;
-        const unsigned dy_rs = (unsigned)(H * p.W * 4), x_rs = dy_rs;      // bytes between channel rows
+        const int H = J.H, W = J.W;
+        const int spr = W >> 4;                               // steps per row
+        const long long dy_img = (long long)(8 * OA) * H * W, x_img = (long long)(8 * IB) * H * W;
+        const unsigned dy_rs = (unsigned)(H * W * 4), x_rs = dy_rs;        // bytes between channel rows
 
         // x image of tap t: window of XP floats starting at column  w0 + al[t],  al[t] = floor4(woff0 + t*wstep);  the
         // fragment reads start ofs[t] = (woff0 + t*wstep) - al[t] floats into it.  Column (half, tap, ib) of lane fr:
@@ -227,10 +227,10 @@ __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
         auto issue = [&](auto stage_c) __attribute__((always_inline)) {
             constexpr int STG = decltype(stage_c)::value;
             const int w0 = l_wi << 4;
-            const float* dyb = J.dy + (long long)l_n * dy_img + (long long)l_h * p.W + w0;
+            const float* dyb = J.dy + (long long)l_n * dy_img + (long long)l_h * W + w0;
             const int hi = l_h + J.hoff;
             const bool rowok = (unsigned)hi < (unsigned)H;
-            const float* xb = J.x + (long long)l_n * x_img + (long long)hi * p.W + (w0 - GW_BIAS);
+            const float* xb = J.x + (long long)l_n * x_img + (long long)hi * W + (w0 - GW_BIAS);
             const int4v dyr = gw_rsrc(dyb), xr = gw_rsrc(xb);
             // the per-lane offsets below are loop-invariant, and hoisted out of the step loop they would cost ~30 registers
             // this kernel does not have: recomputed per step (a dozen VALU per DMA) from a lane id the compiler cannot see through
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
                         const int row = rr / S::XC, ch = rr - row * S::XC;
                         const int wo = J.woff0 + t * J.wstep;
                         const int rel = (wo & ~3) + 4 * ch;           // first column of the piece, relative to w0
-                        const bool ok = rowok && (unsigned)(w0 + rel) <= (unsigned)(p.W - 4);
+                        const bool ok = rowok && (unsigned)(w0 + rel) <= (unsigned)(W - 4);
                         const unsigned voff = ok ? (unsigned)row * x_rs + (unsigned)((GW_BIAS + rel) * 4) : GW_OOB;
                         gw_dma16(lds0 + 2 * S::DYB + STG * S::XB + qx * 1024, voff, xr);
                     }
@@ -544,10 +544,6 @@ static size_t gw_plan(const seld_wgrad_job* jobs, int njobs, GwPlanKind plan[GW_
         GwPlanKind& pk = plan[k];
         if (pk.convs.empty()) continue;
         if (pk.nsubjobs > GW_MAXJ || pk.convs.size() > 24 || pk.total >= (1LL << 30)) return 0;
-        // every launch of a kind shares N and W (the kernel takes them once)
-        const seld_conv_desc& d0 = jobs[pk.convs[0]].desc;
-        for (int c : pk.convs)
-            if (jobs[c].desc.N != d0.N || jobs[c].desc.in[1] != d0.in[1]) return 0;
         pk.nwg = (int)(pk.total < G ? pk.total : G);
         pk.per = (int)((pk.total + pk.nwg - 1) / pk.nwg);
         pk.nwg = (int)((pk.total + pk.per - 1) / pk.per);
@@ -567,8 +563,7 @@ static int gw_launch_kind(const seld_wgrad_job* jobs, const GwPlanKind& pk, int 
     GwP p{};
     GwSumP sp{};
     GwFoldP fp{};
-    const seld_conv_desc& d0 = jobs[pk.convs[0]].desc;
-    p.N = d0.N; p.W = d0.in[1]; p.per = pk.per; p.total = (int)pk.total;
+    p.per = pk.per; p.total = (int)pk.total;
     p.part = (float*)(ws + pk.part_off);
     int nj = 0, step = 0;
     fp.nconv = (int)pk.convs.size();
@@ -583,7 +578,7 @@ static int gw_launch_kind(const seld_wgrad_job* jobs, const GwPlanKind& pk, int 
         for (int kh = 0; kh < KH; ++kh)
             for (int kw0 = 0; kw0 < KWf; kw0 += subKW) {
                 GwJob& j = p.job[nj];
-                j.x = jb.x; j.dy = jb.dy; j.H = d.in[0];
+                j.x = jb.x; j.dy = jb.dy; j.H = d.in[0]; j.W = d.in[1];
                 j.woff0 = kw0 * d.dil[1] - d.pad[1];
                 j.wstep = d.dil[1];
                 j.hoff = kh * d.dil[0] - d.pad[0];
@@ -615,6 +610,15 @@ static int gw_launch_kind(const seld_wgrad_job* jobs, const GwPlanKind& pk, int 
 
 }  // namespace seld
 using namespace seld;
+
+/* Shape family of a convolution in the grouped weight-gradient kernels: 0 = (48, 24, 1x3), 1 = (24, 48, 1x1),
+ * 2 = (24, 24, 3x3), 3 = (48, 48, 1x3) in (Cout/8, Cin/8, kernel); -1 = not taken.  One call of seld_hcq_wgrad_group
+ * makes one persistent launch per family present in its list, so a caller batches by family. */
+extern "C" int seld_hcq_wgrad_group_family(const seld_conv_desc* d) {
+    if (hc_validate(d) != SELD_OK || env().conv_no_hcq) return -1;
+    int nsub;
+    return gw_kind(d, &nsub);
+}
 
 /* Bytes of scratch seld_hcq_wgrad_group needs for this job list; 0 = a job is not a shape these kernels take (the
  * caller then uses the per-layer entry points).  The scratch need not be initialised and is not kept between calls. */

@@ -297,13 +297,95 @@ def wgrad_group(jobs):
     if nbytes == 0:
         return False
     dev = jobs[0][1].device
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _wgrad_group_scratch.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _wgrad_group_scratch[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    if torch.cuda.is_current_stream_capturing():
+        # a recorded step: the scratch comes from (and stays in) the graph's own memory pool
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    else:
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _wgrad_group_scratch.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _wgrad_group_scratch[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     L.check(L.lib().seld_hcq_wgrad_group(arr, len(arr), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.current_stream()),
             "seld_hcq_wgrad_group")
     return True
+
+
+def wgrad_group_family(desc):
+    """Shape family (0..3) of `desc` in the grouped kernels, -1 = not taken (cached)."""
+    key = (bytes(desc), "grp_family")
+    v = _hcq_labels.get(key)
+    if v is None:
+        v = _hcq_labels[key] = int(L.lib().seld_hcq_wgrad_group_family(ctypes.byref(desc)))
+    return v
+
+
+class _DeferredWgrads:
+    """Weight gradients the backward pass does NOT launch where autograd reaches them: the dual-quaternion layers of the
+    TCN and of the 3x3 stages are collected -- (desc, x, dy, gradient slots), the tensors kept alive -- and issued as ONE
+    grouped call (seld_hcq_wgrad_group: one persistent launch per shape family) when the backward pass ends, i.e. before
+    anything reads the gradient buffer (data-parallel exchange, Adam).  Why: a workgroup that keeps a layer's whole output
+    tile in registers needs hundreds of positions to amortise it, and one layer spread over 256 CUs has 64
+    (csrc/hcq_wgrad_grp.hip).  SELD_WGRAD_GROUP=0 restores the per-layer launches on the side stream.
+
+    Families deferred: 0 (192 -> 384 1x3), 1 (384 -> 192 1x1), 2 (192 -> 192 3x3); family 3 (384 -> 384 1x3, tcn.conv2) is
+    three steps per workgroup at its size and stays on the per-layer kernels."""
+    FAMILIES = (0, 1, 2)
+
+    def __init__(self):
+        self.jobs = []
+        self.armed = False
+
+    @staticmethod
+    def enabled():
+        return os.environ.get("SELD_WGRAD_GROUP", "1") != "0"
+
+    def takes(self, desc):
+        return desc.algebra == 8 and self.enabled() and wgrad_group_family(desc) in self.FAMILIES
+
+    def add(self, desc, x, dy, dws):
+        # the stream this backward node runs on produced dy (branch B of the two-stream model runs on its own queue)
+        self.jobs.append((desc, x, dy, list(dws), torch.cuda.current_stream(x.device)))
+        if not self.armed:
+            self.armed = True
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            except RuntimeError:            # not inside a backward pass: issue at once
+                self.flush()
+
+    def flush(self):
+        self.armed = False
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        here = torch.cuda.current_stream(jobs[0][1].device)
+        for st in {j[4] for j in jobs}:
+            if st != here:
+                here.wait_stream(st)
+                for _, x, dy, _, st_ in jobs:
+                    if st_ == st:
+                        x.record_stream(here)
+                        dy.record_stream(here)
+        jobs = [j[:4] for j in jobs]
+        timed = kernel_timer.active and (kernel_timer.only is None or "hcq_wgrad_grp_kernel" in kernel_timer.only)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if not wgrad_group(jobs):            # cannot happen for jobs `takes` accepted; never lose a gradient to it
+            for desc, x, dy, dws in jobs:
+                conv_bwd_weight(desc, x, dy, tuple(dws[0].shape), False, into=dws)
+        elif timed:
+            e1.record()
+            fl = by = 0.0
+            for desc, _, _, _ in jobs:
+                f_, b_ = conv_work(desc, 2)
+                fl, by = fl + f_, by + b_
+            kernel_timer.records.append(("hcq_wgrad_grp_kernel", e0, e1, fl, by))
+
+    def discard(self):
+        self.jobs, self.armed = [], False
+
+
+deferred_wgrads = _DeferredWgrads()
 
 
 def conv_bwd_weight(desc, x, dy, w_shape, want_bias, into=None, bias_into=None):
@@ -445,7 +527,10 @@ def _conv_backward(ctx, dy, first_w):
     dws, dbias = [None] * len(ws), None
     need_w = any(ctx.needs_input_grad[first_w:]) or (ctx.has_bias and ctx.needs_input_grad[1])
     direct = _direct_targets(ws, ctx.bias_param) if need_w else None
-    if direct is not None and _side_enabled() and ctx.needs_input_grad[0]:
+    if direct is not None and direct[1] is None and deferred_wgrads.takes(ctx.desc):
+        deferred_wgrads.add(ctx.desc, x, dy, direct[0])          # issued with the other layers' when the backward pass ends
+        need_w = False
+    elif direct is not None and _side_enabled() and ctx.needs_input_grad[0]:
         _on_side_stream(lambda: conv_bwd_weight(ctx.desc, x, dy, tuple(ws[0].shape), ctx.has_bias, into=direct[0],
                                                 bias_into=direct[1]), x, dy)
         need_w = False
@@ -855,7 +940,10 @@ class HyperConvPairFn(torch.autograd.Function):
         dwsA, dwsB, dbA, dbB = [None] * A, [None] * A, None, None
         if need_w:
             dirA, dirB = _direct_targets(wsA, biasA), _direct_targets(wsB, biasB)
-            if dirA is not None and dirB is not None and dirA[1] is None and dirB[1] is None and _hcq_wgrad_ok(desc, 2):
+            if dirA is not None and dirB is not None and dirA[1] is None and dirB[1] is None and deferred_wgrads.takes(desc):
+                deferred_wgrads.add(desc, x, dyA, dirA[0])
+                deferred_wgrads.add(desc, x, dyB, dirB[0])
+            elif dirA is not None and dirB is not None and dirA[1] is None and dirB[1] is None and _hcq_wgrad_ok(desc, 2):
                 def pair_wgrad_fast():
                     hcq_wgrad_acc(desc, x, dyA, dirA[0], dyB, dirB[0])
                 if _side_enabled():

@@ -101,6 +101,7 @@ class FlatAdam:
 
     def zero_grad(self, set_to_none=False, state=None):
         """`state`: the device-resident step state (hip_ops.philox.state): also advance it (graph-recorded steps)."""
+        H.deferred_wgrads.discard()                  # jobs of a backward pass nobody finished would add into the fresh buffer
         if self.flat_grad.is_cuda:
             H.step_begin(self.flat_grad, state)      # one launch: zero fill (+ step state)
         else:
@@ -114,6 +115,7 @@ class FlatAdam:
         """`state`: take the step number and the learning rate from the device-resident step state instead of the
         host's (graph-recorded steps; GraphedTrainStep keeps the host's count in step and `sync_from_host` pushes host-side
         changes -- eager steps, a restored optimiser -- back into the state before the next replay)."""
+        H.deferred_wgrads.flush()       # grouped weight gradients still pending (a backward pass outside the autograd engine)
         H.join_side_stream()            # weight gradients issued on the side stream (hip_ops._on_side_stream)
         H.hcq_weights.weights_changed() # the packed weight forms of the fast-product convolutions are stale now
         g = self.param_groups[0]
