@@ -33,6 +33,12 @@
 #include <vector>
 #include "hc_common.h"
 
+// GW_DBG: timing experiments of tools/gw_micro.cpp ONLY (parts of the kernel switched off, WRONG results); the library is
+// always built with 0.   1 = no LDS-DMA   2 = no LDS fragment reads   4 = no MFMAs   8 = no barriers
+#ifndef GW_DBG
+#define GW_DBG 0
+#endif
+
 namespace seld {
 
 typedef int int4v __attribute__((ext_vector_type(4)));
@@ -106,13 +112,17 @@ struct GwShape {
     static constexpr int NT = COMB ? 2 * RT * CT : NPR * CTP + (RT - NPR) * CT;
     static constexpr int XC = XP / 4;                      // 16-byte chunks per staged x row
     static constexpr int DYB = 8 * OA * 64;                // bytes of one stage's dy image   [8*OA rows][16]
-    static constexpr int XTB = 8 * IB * XP * 4;            // bytes of one tap's x image      [8*IB rows][XP]
+    // x image of one tap: [8*IB rows][XP floats].  One LDS-DMA instruction covers XR whole rows (lane -> row lane / XC,
+    // piece lane % XC: the same for every instruction); with 5 pieces per row that is 12 rows = 60 lanes, and lanes 60..63
+    // carry the first four pieces of the NEXT 12 rows to where they belong (the next instruction writes the same values
+    // there) -- behind the last rows they fall into 64 bytes of padding.
+    static constexpr int XR = 64 / XC;                     // rows per instruction
+    static constexpr int XTB = 8 * IB * XP * 4 + (64 % XC ? 64 : 0);
     static constexpr int XB = KW * XTB;
-    static constexpr int NDYI = DYB / 1024, XTI = XTB / 1024, NINSTR = NDYI + KW * XTI;
-    static constexpr int LDS_BYTES = 2 * (DYB + XB);
+    static constexpr int NDYI = DYB / 1024, XTI = 8 * IB / XR, NINSTR = NDYI + KW * XTI;
+    static_assert((8 * IB) % XR == 0 && NDYI % 4 == 0 && XTI % 4 == 0, "four loader waves, whole instructions per image");
     static_assert((2 * OA) % 16 == 0 && (2 * IB * KW) % 16 == 0, "tile structure");
-    static_assert(DYB % 1024 == 0 && XTB % 1024 == 0, "an LDS-DMA instruction fills 1 KiB of one image");
-    static_assert(LDS_BYTES <= 160 * 1024, "two stages must fit the CU's LDS");
+    static_assert(DYB % 1024 == 0, "an LDS-DMA instruction fills 1 KiB of the dy image");
     // SPLIT
     __host__ __device__ static constexpr int tile(int i, int j) { return i < NPR ? i * CTP + j : NPR * CTP + (i - NPR) * CT + j; }
     __host__ __device__ static constexpr bool active(int i, int j) { return i >= NPR || j < CTP; }
@@ -123,25 +133,62 @@ struct GwShape {
 // One 16-byte-per-lane LDS-DMA: LDS[lds_addr + 16 * lane ..] <- buffer[voff ..] (zero when voff is out of range).  Inline
 // asm: the compiler's waitcnt pass would otherwise put vmcnt(0) in front of every LDS read that follows (it cannot tell
 // the two stages apart); the kernel counts these loads itself (gw_wait_dma).  M0 is saved and restored in the statement.
-__device__ __forceinline__ void gw_dma16(unsigned lds_addr, unsigned voff, int4v rsrc) {
+__device__ __forceinline__ void gw_dma16(unsigned lds_addr, unsigned voff, int4v rsrc, unsigned soff) {
+    if (GW_DBG & 1) return;
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
+template <int N>
 __device__ __forceinline__ void gw_wait_dma_and_barrier() {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (GW_DBG & 8) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(N) : "memory");
+}
+__device__ __forceinline__ floatx4 gw_mfma(float a, float b, floatx4 c) {
+    if (GW_DBG & 4) { c[0] += a; c[1] += b; return c; }
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// a fragment read; with GW_DBG & 2 the value comes from a register (no LDS instruction)
+// the lane's two floats of half-step u from an x image row: XP == 16 -> swizzled 64-byte rows, one aligned 8-byte read;
+// else the window starts at any column: two 4-byte aligned floats, u * 32 bytes on
+template <int XP>
+__device__ __forceinline__ floatx2 gw_ldx(const unsigned char* base, unsigned off, int u, const unsigned (&sw)[2]) {
+    if (GW_DBG & 2) return (floatx2){__uint_as_float(off), __uint_as_float(off + 1)};
+    if constexpr (XP == 16) {
+        return *reinterpret_cast<const floatx2*>(base + off + sw[u]);
+    } else {
+        const float* q = reinterpret_cast<const float*>(base + off + u * 32);
+        return (floatx2){q[0], q[1]};
+    }
+}
+template <typename T>
+__device__ __forceinline__ T gw_lds(const unsigned char* base, unsigned off) {
+    if (GW_DBG & 2) { T v; for (int i = 0; i < (int)(sizeof(T) / 4); ++i) v[i] = __uint_as_float(off + i); return v; }
+    return *reinterpret_cast<const T*>(base + off);
 }
 __device__ __forceinline__ int4v gw_rsrc(const float* base) {
     const unsigned long long a = (unsigned long long)base;
     return (int4v){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)0x80000000u, 0x00020000};
 }
 
-template <int OA, int IB, int KW, int XP>
+// NSTG = stages of the LDS ring (2, or more where a stage is small: the 1x1 layers' steps are too short for one stage of
+// lead to cover the memory latency).
+template <int OA, int IB, int KW, int XP, int NSTG>
 __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
     using S = GwShape<OA, IB, KW, XP>;
     constexpr int RT = S::RT, CT = S::CT, NT = S::NT;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[S::LDS_BYTES];   // [dy stage 0][dy stage 1][x stage 0][x stage 1]
+    constexpr bool COMB = S::COMB;
+    // Waves 0..3 are the LOADERS (one per SIMD: waves w and w + 4 share one): KD LDS-DMA instructions each per stage.  The
+    // SIMD's other wave loads nothing, so the two partners -- same program, one barrier per step -- do not march in
+    // lockstep through their non-MFMA stretches with the matrix pipe idle (r3d counters: 54 % MFMA busy, 64 % of wave
+    // cycles issue-stalled with every wave loading).
+    constexpr int KD = S::NINSTR / 4;
+    static_assert(NSTG >= 2 && (NSTG - 2) * KD <= 63, "vmcnt is a 6-bit count");
+    static_assert(NSTG * (S::DYB + S::XB) <= 160 * 1024, "the ring must fit the CU's LDS");
+    // [dy stage 0 .. NSTG-1][x stage 0 .. NSTG-1]
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTG * (S::DYB + S::XB)];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    constexpr unsigned XBASE = NSTG * S::DYB;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,25 +211,41 @@ __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
     // ---- lane constants of the fragment reads ------------------------------------------------------------------------
     // A step's 16 positions are multiplied in two halves of 8 (two MFMA k-steps each): in half u, lane (fr, fk) supplies
     // positions 8*u + 2*fk + {0, 1} of row / column 16*tile + fr -- 8-byte reads, half the operand registers of a
-    // 16-position pass (the 42-tile layers have 168 accumulators per lane).
-    // dy image: row (half*4 + c)*OA + o, 64 bytes per row
-    // (OA a multiple of 16: no row tile mixes primal and dual rows, the tiles differ by compile-time offsets from ONE lane
-    // register; otherwise one register per tile)
-    constexpr bool COMB = S::COMB;
+    // 16-position pass.  dy image: row (half*4 + c)*OA + o, 64 bytes per row.  COMB: the row tiles differ by compile-time
+    // offsets from ONE lane register; SPLIT: one register per tile (the middle tile mixes primal and dual rows).
+    // Bank conflicts: with 64-byte rows the 16 rows a read touches fall on 4 bank groups (r3g: the LDS array was busy with
+    // conflicts 72 % of the 1x1 kernel's time, the LDS phase cost as much as the MFMAs).  The 16-byte pieces of a row are
+    // therefore XOR-swizzled: logical piece c of image row R is stored at piece  c ^ ((R >> 2) & 3).  The LDS image stays
+    // lane-linear for the DMA -- the loader swaps which piece of its row a lane FETCHES (R >> 2 & 3 = lane >> 4 & 3 there,
+    // whatever the instruction) -- and a ds_read_b64 of 16 rows x {2 pieces halves} covers all 64 banks once.
+    // In half u, lane (fr, fk) reads logical piece 2u + (fk >> 1), bytes 8 * (fk & 1) .. +7 of it.
+    // COMB (OA a multiple of 16): R >> 2 & 3 = fr >> 2 & 3 for every row tile and component: ONE register per half.
+    // SPLIT: R = (half*4 + comp)*OA + o depends on the component: one register per (row tile, component slot, half).
+    const unsigned a_c1 = (unsigned)(ca1 * OA * 64), a_c2 = (unsigned)(ca2 * OA * 64);
+    unsigned sw[2];                                                      // the swizzled piece + byte offset for sigma = fr >> 2 & 3
+#pragma unroll
+    for (int u = 0; u < 2; ++u) sw[u] = (unsigned)((((2 * u + (fk >> 1)) ^ ((fr >> 2) & 3)) << 4) + ((fk & 1) << 3));
     constexpr int NAR = COMB ? 1 : RT;
-    unsigned arow_[NAR];
+    unsigned arow_[NAR][2][2];
 #pragma unroll
     for (int i = 0; i < NAR; ++i) {
         const int r = 16 * i + fr;
         const int half = r >= OA ? 1 : 0;
-        arow_[i] = (unsigned)(((half * 4 * OA + (r - half * OA)) * 16 + 2 * fk) * 4);
+        const int o = r - half * OA;
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs) {
+            const int R = (half * 4 + (cs ? ca2 : ca1)) * OA + o;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                arow_[i][cs][u] = COMB ? (unsigned)(fr * 64) + sw[u]
+                                       : (unsigned)(R * 64 + (((2 * u + (fk >> 1)) ^ ((R >> 2) & 3)) << 4) + ((fk & 1) << 3));
+        }
     }
-    // SPLIT: row tile i of [dy_p; dy_d];  COMB: row tile i of the half `half`
-    auto arow = [&](int i, int half) __attribute__((always_inline)) -> unsigned {
-        if constexpr (COMB) return arow_[0] + (unsigned)((half * 4 * OA + 16 * i) * 64);
-        else return arow_[i];
+    // byte address (inside a stage's dy image) of this lane's 8 bytes: row tile i (COMB: of half `half`), component slot cs, half-step u
+    auto arow = [&](int i, int half, int cs, int u) __attribute__((always_inline)) -> unsigned {
+        if constexpr (COMB) return arow_[0][0][u] + (unsigned)((half * 4 * OA + 16 * i) * 64) + (cs ? a_c2 : a_c1);
+        else return arow_[i][cs][u];
     };
-    const unsigned a_c1 = (unsigned)(ca1 * OA * 64), a_c2 = (unsigned)(ca2 * OA * 64);
     const unsigned b_c1 = (unsigned)(cb1 * IB * XP * 4), b_c2 = (unsigned)(cb2 * IB * XP * 4);
 
     for (int g = g0; g < g1;) {
@@ -195,10 +258,10 @@ __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
         const long long dy_img = (long long)(8 * OA) * H * W, x_img = (long long)(8 * IB) * H * W;
         const unsigned dy_rs = (unsigned)(H * W * 4), x_rs = dy_rs;        // bytes between channel rows
 
-        // x image of tap t: window of XP floats starting at column  w0 + al[t],  al[t] = floor4(woff0 + t*wstep);  the
-        // fragment reads start ofs[t] = (woff0 + t*wstep) - al[t] floats into it.  Column (half, tap, ib) of lane fr:
-        // (COMB: the CT column tiles of the primal half; the dual half lies 4*IB image rows further; columns past IB*KW in
-        // the last tile read column 0 -- their products land in output columns the fold never looks at)
+        // x image of tap t: window of XP floats starting at column  w0 + floor4(woff0 + t*wstep);  the fragment reads start
+        // (woff0 + t*wstep) & 3 floats into it.  Column (half, tap, ib) of lane fr.  (COMB: the CT column tiles of the primal
+        // half; the dual half lies 4*IB image rows further; columns past IB*KW in the last tile read column 0 -- their
+        // products land in output columns the fold never looks at.)
         unsigned bcol[CT];
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
@@ -209,14 +272,18 @@ __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
             const int t = cc / IB, ib = cc - t * IB;
             const int wo = J.woff0 + t * J.wstep;
             const int ofs = wo & 3;
-            bcol[j] = (unsigned)((((t * 8 + half * 4) * IB + ib) * XP + ofs + 2 * fk) * 4);
+            // XP == 16 (aligned windows, 64-byte rows): the same swizzle as the dy image, sigma = ib >> 2 & 3 = fr >> 2 & 3
+            // (IB and IB*KW multiples of 16 there), added per half-step from sw[]
+            if constexpr (XP == 16) bcol[j] = (unsigned)(t * S::XTB + (half * 4 * IB + ib) * 64);
+            else bcol[j] = (unsigned)(t * S::XTB + ((half * 4 * IB + ib) * XP + ofs + 2 * fk) * 4);
         }
 
         floatx4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-        // wave-uniform tracker of the step to LOAD next
+        // ---- the loader: wave-uniform tracker of the step to LOAD next, and that step's descriptors -----------------------
+        const bool loader = wave < 4;
         int l_wi, l_h, l_n;
         {
             const int row = s_beg / spr;
@@ -224,74 +291,127 @@ __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
             l_n = row / H;
             l_h = row - l_n * H;
         }
-        auto issue = [&](auto stage_c) __attribute__((always_inline)) {
-            constexpr int STG = decltype(stage_c)::value;
+        // lane parts of the buffer offsets (bytes): dy piece (row lane >> 2, piece lane & 3); x piece (row lane / XC, piece
+        // lane % XC), and the same with lanes >= XR * XC switched off for the last instruction of an image
+        // (swizzle: the lane that WRITES piece lane & 3 of its row fetches piece (lane & 3) ^ (lane >> 4 & 3))
+        const unsigned ldy = (unsigned)(lane >> 2) * dy_rs + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
+        const int lch = S::XC == 4 ? ((lane & 3) ^ ((lane >> 4) & 3)) : lane % S::XC;
+        const unsigned lx = (unsigned)(lane / S::XC) * x_rs + (unsigned)lch * 16u;
+        const unsigned lx_last = lane < S::XR * S::XC ? lx : GW_OOB;
+        const unsigned x_blk = (unsigned)S::XR * x_rs;                 // bytes between the row blocks of two instructions
+        int al[KW];                                                     // first column of tap t's window, relative to w0
+#pragma unroll
+        for (int t = 0; t < KW; ++t) al[t] = (J.woff0 + t * J.wstep) & ~3;
+        int4v dyr, xr;
+        int lo[KW], hi[KW];                                             // valid pieces of tap t's rows in the step being loaded
+        auto load_begin = [&]() __attribute__((always_inline)) {
             const int w0 = l_wi << 4;
             const float* dyb = J.dy + (long long)l_n * dy_img + (long long)l_h * W + w0;
-            const int hi = l_h + J.hoff;
-            const bool rowok = (unsigned)hi < (unsigned)H;
-            const float* xb = J.x + (long long)l_n * x_img + (long long)hi * W + (w0 - GW_BIAS);
-            const int4v dyr = gw_rsrc(dyb), xr = gw_rsrc(xb);
-            // the per-lane offsets below are loop-invariant, and hoisted out of the step loop they would cost ~30 registers
-            // this kernel does not have: recomputed per step (a dozen VALU per DMA) from a lane id the compiler cannot see through
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
+            const int hi_ = l_h + J.hoff;
+            const bool rowok = (unsigned)hi_ < (unsigned)H;
+            const float* xb = J.x + (long long)l_n * x_img + (long long)hi_ * W + (w0 - GW_BIAS);
+            dyr = gw_rsrc(dyb);
+            xr = gw_rsrc(xb);
 #pragma unroll
-            for (int k = 0; k < (S::NINSTR + 7) / 8; ++k) {
-                const int q = k * 8 + wave;                           // instruction index, wave-uniform
-                if (q < S::NINSTR) {
-                    if (q < S::NDYI) {
-                        const int c = q * 64 + ln;                    // chunk: row c >> 2, 16-byte piece c & 3
-                        const unsigned voff = (unsigned)(c >> 2) * dy_rs + (unsigned)(c & 3) * 16u;
-                        gw_dma16(lds0 + STG * S::DYB + q * 1024, voff, dyr);
-                    } else {
-                        const int qx = q - S::NDYI;
-                        const int t = qx / S::XTI;                    // tap, wave-uniform (XTI instructions per tap image)
-                        const int rr = (qx - t * S::XTI) * 64 + ln;
-                        const int row = rr / S::XC, ch = rr - row * S::XC;
-                        const int wo = J.woff0 + t * J.wstep;
-                        const int rel = (wo & ~3) + 4 * ch;           // first column of the piece, relative to w0
-                        const bool ok = rowok && (unsigned)(w0 + rel) <= (unsigned)(W - 4);
-                        const unsigned voff = ok ? (unsigned)row * x_rs + (unsigned)((GW_BIAS + rel) * 4) : GW_OOB;
-                        gw_dma16(lds0 + 2 * S::DYB + STG * S::XB + qx * 1024, voff, xr);
-                    }
-                }
+            for (int t = 0; t < KW; ++t) {
+                const int c0 = w0 + al[t];                            // a multiple of 4; piece ch covers columns c0 + 4ch .. +3
+                int l = c0 < 0 ? (-c0) >> 2 : 0;
+                int h = (W - 4 - c0) >> 2;                            // last piece that ends inside the row (may be < 0)
+                if (h > S::XC - 1) h = S::XC - 1;
+                // piece ch is valid iff (unsigned)(ch - lo) <= (unsigned)hi, hi >= 0; an EMPTY range (window wholly outside
+                // the row, or the input row outside the image) gets lo beyond every ch: the difference wraps to a huge value
+                const bool none = !rowok || h < l;
+                lo[t] = none ? (1 << 20) : l;
+                hi[t] = none ? 0 : h - l;
             }
             if (++l_wi == spr) { l_wi = 0; if (++l_h == H) { l_h = 0; ++l_n; } }
         };
-        auto compute = [&](auto stage_c) __attribute__((always_inline)) {
+        // DMA number K (of KD) of a loader wave for the step load_begin() described, into stage STG: instruction 4K + wave.
+        // (NDYI and XTI are multiples of 4: whether it is a dy or an x instruction, and of which tap, is compile-time.)
+        auto dma = [&](auto stage_c, auto k_c) __attribute__((always_inline)) {
+            constexpr int STG = decltype(stage_c)::value;
+            constexpr int K = decltype(k_c)::value;
+            constexpr int Q0 = 4 * K;
+            if constexpr (Q0 < S::NDYI) {
+                const unsigned q = (unsigned)(Q0 + wave);
+                gw_dma16(lds0 + STG * S::DYB + q * 1024u, ldy, dyr, q * 16u * dy_rs);
+            } else {
+                constexpr int T = (Q0 - S::NDYI) / S::XTI;
+                const unsigned e = (unsigned)(Q0 - S::NDYI - T * S::XTI + wave);        // row block inside the tap image
+                unsigned v = (e == S::XTI - 1) ? lx_last : lx;
+                v = ((unsigned)(lch - lo[T]) <= (unsigned)hi[T]) ? v : GW_OOB;
+                gw_dma16(lds0 + XBASE + STG * S::XB + T * S::XTB + e * (unsigned)(S::XR * S::XC * 16), v, xr,
+                         e * x_blk + (unsigned)((GW_BIAS + al[T]) * 4));
+            }
+        };
+        // DMAs [K0, K1) -- compile-time range
+        auto dma_range = [&](auto stage_c, auto k0_c, auto k1_c) __attribute__((always_inline)) {
+            constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
+            if constexpr (K0 < K1) {
+                dma(stage_c, std::integral_constant<int, K0>{});
+                if constexpr (K0 + 1 < K1) dma(stage_c, std::integral_constant<int, K0 + 1>{});
+                if constexpr (K0 + 2 < K1) dma(stage_c, std::integral_constant<int, K0 + 2>{});
+                if constexpr (K0 + 3 < K1) dma(stage_c, std::integral_constant<int, K0 + 3>{});
+                if constexpr (K0 + 4 < K1) dma(stage_c, std::integral_constant<int, K0 + 4>{});
+                if constexpr (K0 + 5 < K1) dma(stage_c, std::integral_constant<int, K0 + 5>{});
+                static_assert(K1 - K0 <= 6, "at most six DMAs per slot");
+            }
+        };
+        auto load_all = [&](auto stage_c) __attribute__((always_inline)) {
+            if (loader) {
+                load_begin();
+                dma_range(stage_c, std::integral_constant<int, 0>{}, std::integral_constant<int, (KD < 6 ? KD : 6)>{});
+                dma_range(stage_c, std::integral_constant<int, (KD < 6 ? KD : 6)>{}, std::integral_constant<int, (KD < 12 ? KD : 12)>{});
+                dma_range(stage_c, std::integral_constant<int, (KD < 12 ? KD : 12)>{}, std::integral_constant<int, KD>{});
+                static_assert(KD <= 18, "load_all is unrolled for up to eighteen DMAs per loader wave");
+            }
+        };
+
+        // ---- one step: the MFMAs of stage STG; the DMAs of the step NSTG-1 ahead are spread over its MFMA blocks ------------
+        // Block b of NB gets DMAs [b*KD/NB, (b+1)*KD/NB): issued right behind the block's MFMAs they cost ~60 cycles each
+        // instead of a burst of KD at the top of the step with the matrix pipe idle.
+        auto compute = [&](auto stage_c, auto lstage_c, bool more) __attribute__((always_inline)) {
             constexpr int STG = decltype(stage_c)::value;
             const unsigned char* dyi = smem + STG * S::DYB;
-            const unsigned char* xi = smem + 2 * S::DYB + STG * S::XB;
+            const unsigned char* xi = smem + XBASE + STG * S::XB;
+            more = more && loader;
+            if (more) load_begin();
             if constexpr (!COMB) {
-                // Column tiles in groups of GC: the raw reads + sums of group g+1 are issued in front of group g's MFMAs (one
-                // scheduling region), so a wave holds 2 * GC column operands, not CT of them.
-                constexpr int GC = 3, NG = CT / GC;
+                // SPLIT.  Column tiles in groups of GC: the raw reads of group g+1 are issued in front of group g's MFMAs and
+                // summed behind them, so their LDS latency lies under the MFMAs.
+                constexpr int GC = 3, NG = CT / GC, NB = 2 * NG;
                 static_assert(COMB || CT % GC == 0, "column tiles come in groups of three");
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    floatx2 F[RT], G[2][GC];
-                    auto read_g = [&](auto grp_c) __attribute__((always_inline)) {
+                    floatx2 F[RT], G[GC], r1[GC], r2[GC];
+                    auto read_raw = [&](auto grp_c) __attribute__((always_inline)) {
                         constexpr int GRP = decltype(grp_c)::value;
 #pragma unroll
                         for (int jj = 0; jj < GC; ++jj) {
-                            const float* q1 = reinterpret_cast<const float*>(xi + bcol[GRP * GC + jj] + b_c1 + u * 32);
-                            const float* q2 = reinterpret_cast<const float*>(xi + bcol[GRP * GC + jj] + b_c2 + u * 32);
-                            G[GRP & 1][jj][0] = q1[0] + tb * q2[0];
-                            G[GRP & 1][jj][1] = q1[1] + tb * q2[1];
+                            r1[jj] = gw_ldx<XP>(xi, bcol[GRP * GC + jj] + b_c1, u, sw);
+                            r2[jj] = gw_ldx<XP>(xi, bcol[GRP * GC + jj] + b_c2, u, sw);
                         }
+                    };
+                    auto form_g = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                        for (int jj = 0; jj < GC; ++jj) G[jj] = r1[jj] + tb * r2[jj];
                     };
 #pragma unroll
                     for (int i = 0; i < RT; ++i) {
-                        const floatx2 v1 = *reinterpret_cast<const floatx2*>(dyi + arow(i, 0) + a_c1 + u * 32);
-                        const floatx2 v2 = *reinterpret_cast<const floatx2*>(dyi + arow(i, 0) + a_c2 + u * 32);
+                        const floatx2 v1 = gw_lds<floatx2>(dyi, arow(i, 0, 0, u));
+                        const floatx2 v2 = gw_lds<floatx2>(dyi, arow(i, 0, 1, u));
                         F[i] = v1 + sa2 * v2;
                     }
-                    read_g(std::integral_constant<int, 0>{});
-                    __builtin_amdgcn_sched_barrier(0);
+                    read_raw(std::integral_constant<int, 0>{});
+                    form_g();
                     auto group = [&](auto grp_c) __attribute__((always_inline)) {
                         constexpr int GRP = decltype(grp_c)::value;
-                        if constexpr (GRP + 1 < NG) read_g(std::integral_constant<int, GRP + 1>{});
+                        constexpr int BLK = 0;
+                        floatx2 Gc[GC];
+#pragma unroll
+                        for (int jj = 0; jj < GC; ++jj) Gc[jj] = G[jj];
+                        if constexpr (GRP + 1 < NG) read_raw(std::integral_constant<int, GRP + 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -299,86 +419,131 @@ __global__ __launch_bounds__(512, 2) void hcq_wgrad_grp_kernel(const GwP p) {
 #pragma unroll
                                 for (int jj = 0; jj < GC; ++jj)
                                     if (S::active(i, GRP * GC + jj))
-                                        acc[S::tile(i, GRP * GC + jj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                            F[i][s], G[GRP & 1][jj][s], acc[S::tile(i, GRP * GC + jj)], 0, 0, 0);
+                                        acc[S::tile(i, GRP * GC + jj)] = gw_mfma(
+                                            F[i][s], Gc[jj][s], acc[S::tile(i, GRP * GC + jj)]);
+                        (void)BLK;
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (GRP + 1 < NG) form_g();
+                    };
+                    // with two stages the step's DMAs all go into the FIRST half-step: the next step opens with vmcnt(0), and a
+                    // DMA issued behind the last MFMA block would expose its whole memory latency there, every step
+                    constexpr int NSLOT = NSTG > 2 ? NB : NG;
+                    auto slot = [&](auto b_c) __attribute__((always_inline)) {
+                        constexpr int B = decltype(b_c)::value;
+                        if constexpr (B < NSLOT)
+                            if (more) dma_range(lstage_c, std::integral_constant<int, B * KD / NSLOT>{}, std::integral_constant<int, (B + 1) * KD / NSLOT>{});
                     };
                     group(std::integral_constant<int, 0>{});
-                    if constexpr (NG > 1) group(std::integral_constant<int, 1>{});
-                    if constexpr (NG > 2) group(std::integral_constant<int, 2>{});
+                    if (u == 0) slot(std::integral_constant<int, 0>{}); else slot(std::integral_constant<int, NG>{});
+                    if constexpr (NG > 1) {
+                        group(std::integral_constant<int, 1>{});
+                        if (u == 0) slot(std::integral_constant<int, 1>{}); else slot(std::integral_constant<int, NG + 1>{});
+                    }
+                    if constexpr (NG > 2) {
+                        group(std::integral_constant<int, 2>{});
+                        if (u == 0) slot(std::integral_constant<int, 2>{}); else slot(std::integral_constant<int, NG + 2>{});
+                    }
                     static_assert(NG <= 3, "unrolled by hand up to three groups");
                 }
             } else {
-                // One column tile at a time: its primal and dual operands (G_p, G_d) of tile j+1 are read in front of tile
-                // j's 3 * RT * 2 MFMAs.  Per k-step and row tile: accQ += F_p G_p, accQ += F_d G_d, accQ2 += F_d G_p -- the
-                // two products into the same accumulator are RT MFMAs apart (dependent latency 40 cycles, issue 32).
+                // COMB.  One column tile at a time: its primal and dual operands of tile j+1 are read in front of tile j's
+                // 3 * RT * 2 MFMAs and summed behind them.  Per k-step and row tile: accQ += F_p G_p, accQ2 += F_d G_p,
+                // accQ += F_d G_d -- the two products into the same accumulator are 2 * RT MFMAs apart.
                 constexpr unsigned DHALF = (unsigned)(4 * IB * XP * 4);
+                constexpr int NB = 2 * CT;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    floatx2 Fp[RT], Fd[RT], Gp[2], Gd[2];
-                    auto read_g = [&](auto j_c) __attribute__((always_inline)) {
+                    floatx2 Fp[RT], Fd[RT], Gp, Gd, rp1, rp2, rd1, rd2;
+                    auto read_raw = [&](auto j_c) __attribute__((always_inline)) {
                         constexpr int JJ = decltype(j_c)::value;
-                        const float* p1 = reinterpret_cast<const float*>(xi + bcol[JJ] + b_c1 + u * 32);
-                        const float* p2 = reinterpret_cast<const float*>(xi + bcol[JJ] + b_c2 + u * 32);
-                        const float* d1 = reinterpret_cast<const float*>(xi + bcol[JJ] + b_c1 + DHALF + u * 32);
-                        const float* d2 = reinterpret_cast<const float*>(xi + bcol[JJ] + b_c2 + DHALF + u * 32);
-                        Gp[JJ & 1][0] = p1[0] + tb * p2[0];
-                        Gp[JJ & 1][1] = p1[1] + tb * p2[1];
-                        Gd[JJ & 1][0] = d1[0] + tb * d2[0];
-                        Gd[JJ & 1][1] = d1[1] + tb * d2[1];
+                        rp1 = gw_ldx<XP>(xi, bcol[JJ] + b_c1, u, sw);
+                        rp2 = gw_ldx<XP>(xi, bcol[JJ] + b_c2, u, sw);
+                        rd1 = gw_ldx<XP>(xi, bcol[JJ] + b_c1 + DHALF, u, sw);
+                        rd2 = gw_ldx<XP>(xi, bcol[JJ] + b_c2 + DHALF, u, sw);
+                    };
+                    auto form_g = [&]() __attribute__((always_inline)) {
+                        Gp = rp1 + tb * rp2;
+                        Gd = rd1 + tb * rd2;
                     };
 #pragma unroll
                     for (int i = 0; i < RT; ++i) {
-                        const floatx2 p1 = *reinterpret_cast<const floatx2*>(dyi + arow(i, 0) + a_c1 + u * 32);
-                        const floatx2 p2 = *reinterpret_cast<const floatx2*>(dyi + arow(i, 0) + a_c2 + u * 32);
-                        const floatx2 d1 = *reinterpret_cast<const floatx2*>(dyi + arow(i, 1) + a_c1 + u * 32);
-                        const floatx2 d2 = *reinterpret_cast<const floatx2*>(dyi + arow(i, 1) + a_c2 + u * 32);
+                        const floatx2 p1 = gw_lds<floatx2>(dyi, arow(i, 0, 0, u));
+                        const floatx2 p2 = gw_lds<floatx2>(dyi, arow(i, 0, 1, u));
+                        const floatx2 d1 = gw_lds<floatx2>(dyi, arow(i, 1, 0, u));
+                        const floatx2 d2 = gw_lds<floatx2>(dyi, arow(i, 1, 1, u));
                         Fp[i] = p1 + sa2 * p2;
                         Fd[i] = d1 + sa2 * d2;
                     }
-                    read_g(std::integral_constant<int, 0>{});
-                    __builtin_amdgcn_sched_barrier(0);
+                    read_raw(std::integral_constant<int, 0>{});
+                    form_g();
                     auto column = [&](auto j_c) __attribute__((always_inline)) {
                         constexpr int JJ = decltype(j_c)::value;
-                        if constexpr (JJ + 1 < CT) read_g(std::integral_constant<int, JJ + 1>{});
+                        const floatx2 gp = Gp, gd = Gd;
+                        if constexpr (JJ + 1 < CT) read_raw(std::integral_constant<int, JJ + 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int s = 0; s < 2; ++s) {
 #pragma unroll
                             for (int i = 0; i < RT; ++i)
-                                acc[S::tileq(0, i, JJ)] = __builtin_amdgcn_mfma_f32_16x16x4f32(Fp[i][s], Gp[JJ & 1][s], acc[S::tileq(0, i, JJ)], 0, 0, 0);
+                                acc[S::tileq(0, i, JJ)] = gw_mfma(Fp[i][s], gp[s], acc[S::tileq(0, i, JJ)]);
 #pragma unroll
                             for (int i = 0; i < RT; ++i)
-                                acc[S::tileq(1, i, JJ)] = __builtin_amdgcn_mfma_f32_16x16x4f32(Fd[i][s], Gp[JJ & 1][s], acc[S::tileq(1, i, JJ)], 0, 0, 0);
+                                acc[S::tileq(1, i, JJ)] = gw_mfma(Fd[i][s], gp[s], acc[S::tileq(1, i, JJ)]);
 #pragma unroll
                             for (int i = 0; i < RT; ++i)
-                                acc[S::tileq(0, i, JJ)] = __builtin_amdgcn_mfma_f32_16x16x4f32(Fd[i][s], Gd[JJ & 1][s], acc[S::tileq(0, i, JJ)], 0, 0, 0);
+                                acc[S::tileq(0, i, JJ)] = gw_mfma(Fd[i][s], gd[s], acc[S::tileq(0, i, JJ)]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (JJ + 1 < CT) form_g();
+                    };
+                    constexpr int NSLOT = NSTG > 2 ? NB : CT;          // two stages: all DMAs in the first half-step (see SPLIT)
+                    auto slot = [&](auto b_c) __attribute__((always_inline)) {
+                        constexpr int B = decltype(b_c)::value;
+                        if constexpr (B < NSLOT)
+                            if (more) dma_range(lstage_c, std::integral_constant<int, B * KD / NSLOT>{}, std::integral_constant<int, (B + 1) * KD / NSLOT>{});
                     };
                     column(std::integral_constant<int, 0>{});
-                    if constexpr (CT > 1) column(std::integral_constant<int, 1>{});
-                    if constexpr (CT > 2) column(std::integral_constant<int, 2>{});
-                    if constexpr (CT > 3) column(std::integral_constant<int, 3>{});
-                    if constexpr (CT > 4) column(std::integral_constant<int, 4>{});
+                    if (u == 0) slot(std::integral_constant<int, 0>{}); else slot(std::integral_constant<int, CT>{});
+                    if constexpr (CT > 1) {
+                        column(std::integral_constant<int, 1>{});
+                        if (u == 0) slot(std::integral_constant<int, 1>{}); else slot(std::integral_constant<int, CT + 1>{});
+                    }
+                    if constexpr (CT > 2) {
+                        column(std::integral_constant<int, 2>{});
+                        if (u == 0) slot(std::integral_constant<int, 2>{}); else slot(std::integral_constant<int, CT + 2>{});
+                    }
+                    if constexpr (CT > 3) {
+                        column(std::integral_constant<int, 3>{});
+                        if (u == 0) slot(std::integral_constant<int, 3>{}); else slot(std::integral_constant<int, CT + 3>{});
+                    }
+                    if constexpr (CT > 4) {
+                        column(std::integral_constant<int, 4>{});
+                        if (u == 0) slot(std::integral_constant<int, 4>{}); else slot(std::integral_constant<int, CT + 4>{});
+                    }
                     static_assert(CT <= 5, "unrolled by hand up to five column tiles");
                 }
             }
         };
-        using ST0 = std::integral_constant<int, 0>;
-        using ST1 = std::integral_constant<int, 1>;
 
         // every wave has left the previous job's last compute before its LDS images are overwritten
         asm volatile("s_barrier" ::: "memory");
-        issue(ST0{});
-        for (int s = s_beg; s < s_end; s += 2) {
-            gw_wait_dma_and_barrier();                      // step s landed (all waves); everybody is done with stage 1
-            if (s + 1 < s_end) issue(ST1{});
-            compute(ST0{});
-            if (s + 1 < s_end) {
-                gw_wait_dma_and_barrier();
-                if (s + 2 < s_end) issue(ST0{});
-                compute(ST1{});
-            }
+        // prologue: the first NSTG-1 steps' loads
+        if (s_beg + 0 < s_end) load_all(std::integral_constant<int, 0>{});
+        if constexpr (NSTG > 2) { if (s_beg + 1 < s_end) load_all(std::integral_constant<int, 1>{}); }
+        if constexpr (NSTG > 3) { if (s_beg + 2 < s_end) load_all(std::integral_constant<int, 2>{}); }
+        static_assert(NSTG <= 4, "prologue unrolled for up to four stages");
+        auto step = [&](int s, auto r_c) __attribute__((always_inline)) {
+            constexpr int R = decltype(r_c)::value;
+            // the loads of steps s .. s+NSTG-2 are in flight (fewer at the end of the range): wait for the oldest stage
+            if (s_end - s >= NSTG - 1) gw_wait_dma_and_barrier<(NSTG - 2) * KD>();
+            else gw_wait_dma_and_barrier<0>();
+            compute(r_c, std::integral_constant<int, (R + NSTG - 1) % NSTG>{}, s + NSTG - 1 < s_end);
+        };
+        for (int s = s_beg; s < s_end; s += NSTG) {
+            step(s, std::integral_constant<int, 0>{});
+            if (s + 1 < s_end) step(s + 1, std::integral_constant<int, 1>{});
+            if constexpr (NSTG > 2) { if (s + 2 < s_end) step(s + 2, std::integral_constant<int, 2>{}); }
+            if constexpr (NSTG > 3) { if (s + 3 < s_end) step(s + 3, std::integral_constant<int, 3>{}); }
         }
 
         // ---- flush: accumulator fragments as they stand, 16 bytes per lane, slot = workgroup + job ----------------------
@@ -557,7 +722,7 @@ static size_t gw_plan(const seld_wgrad_job* jobs, int njobs, GwPlanKind plan[GW_
     return off;
 }
 
-template <int OA, int IB, int KW, int XP>
+template <int OA, int IB, int KW, int XP, int NSTG>
 static int gw_launch_kind(const seld_wgrad_job* jobs, const GwPlanKind& pk, int subKW, unsigned char* ws, hipStream_t st) {
     using S = GwShape<OA, IB, KW, XP>;
     GwP p{};
@@ -590,7 +755,7 @@ static int gw_launch_kind(const seld_wgrad_job* jobs, const GwPlanKind& pk, int 
     }
     sp.step0[nj] = step;
     p.njobs = nj;
-    hipLaunchKernelGGL((hcq_wgrad_grp_kernel<OA, IB, KW, XP>), dim3(pk.nwg), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((hcq_wgrad_grp_kernel<OA, IB, KW, XP, NSTG>), dim3(pk.nwg), dim3(512), 0, st, p);
     int rc = check_launch();
     if (rc) return rc;
     sp.part = p.part; sp.red = (float*)(ws + pk.red_off); sp.njobs = nj; sp.per = pk.per; sp.total = (int)pk.total;
@@ -647,9 +812,9 @@ extern "C" int seld_hcq_wgrad_group(const seld_wgrad_job* jobs, int32_t njobs, v
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)workspace;
     int rc = SELD_OK;
-    if (!plan[GW_K_48_24_3].convs.empty()) rc = gw_launch_kind<48, 24, 3, 20>(jobs, plan[GW_K_48_24_3], 3, ws, st);
-    if (!rc && !plan[GW_K_24_48_1].convs.empty()) rc = gw_launch_kind<24, 48, 1, 16>(jobs, plan[GW_K_24_48_1], 1, ws, st);
-    if (!rc && !plan[GW_K_24_24_3].convs.empty()) rc = gw_launch_kind<24, 24, 3, 20>(jobs, plan[GW_K_24_24_3], 3, ws, st);
-    if (!rc && !plan[GW_K_48_48_1S].convs.empty()) rc = gw_launch_kind<48, 48, 1, 20>(jobs, plan[GW_K_48_48_1S], 1, ws, st);
+    if (!plan[GW_K_48_24_3].convs.empty()) rc = gw_launch_kind<48, 24, 3, 20, 2>(jobs, plan[GW_K_48_24_3], 3, ws, st);
+    if (!rc && !plan[GW_K_24_48_1].convs.empty()) rc = gw_launch_kind<24, 48, 1, 16, 4>(jobs, plan[GW_K_24_48_1], 1, ws, st);
+    if (!rc && !plan[GW_K_24_24_3].convs.empty()) rc = gw_launch_kind<24, 24, 3, 20, 2>(jobs, plan[GW_K_24_24_3], 3, ws, st);
+    if (!rc && !plan[GW_K_48_48_1S].convs.empty()) rc = gw_launch_kind<48, 48, 1, 20, 2>(jobs, plan[GW_K_48_48_1S], 1, ws, st);
     return rc;
 }
