@@ -144,6 +144,15 @@ MODEL_CASES += [
          time_dim=64, full_grads=["seld_block.cnn.2.0.j_weight", "seld_block.tcn.ResBlocks.0.conv1_filter.r_weight"]),
 ]
 
+# config 1 (BASELINE's CPU-runnable case): real-valued SELD-TCN at the config widths 64 / G128 / U64 / V128, real classifier
+# (/root/reference/config/SERVER_SELD-TCN-S1-PHI_8ch.txt) -- the real-valued layers at widths the 16-wide tiny_R never reaches
+MODEL_CASES += [
+    dict(_WIDE, name="c1w_train", domain="R", domain_classifier="R", input_channels=8, cnn_filters=[64, 64, 64], G=128,
+         U=64, V=[128, 128], fc_layers=[128],
+         full_grads=["seld_block.cnn.0.0.weight", "seld_block.tcn.ResBlocks.6.conv1_gate.weight",
+                     "seld_block.tcn.ResBlocks.2.conv2_skip.weight", "doa.0.weight"]),
+]
+
 _NON_CTOR = {"name", "B", "train", "taps", "full_grads", "fill", "grad_tol"}
 
 

@@ -136,3 +136,32 @@ def test_flat_adam_aliases_parameters():
     for _ in range(4):
         s.step()
     assert abs(opt.param_groups[0]["lr"] - 0.25e-3) < 1e-12
+
+
+def test_shapes_beyond_32bit_offsets_are_not_given_to_the_fast_kernels():
+    """The fast-product kernels index a tensor with 32-bit byte offsets (csrc/hcq_conv.hip, hcq_wgrad_grp.hip): the host must
+    refuse them a tensor of 4 GB or more -- e.g. the first layer at batch 64, F = 256 (6.4 GB of output; /root/reference
+    model.py:273-283 at twice the benchmark batch) -- so that such a call runs on the 64-bit-indexed generic kernels instead.
+    Host-side queries only: nothing is launched."""
+    import ctypes
+    pkg = importlib.import_module(PKG)
+    H, L = pkg.hip_ops, pkg._lib
+    big = H.make_conv_desc((64, 8, 256, 512), 192, 8, (3, 3), 1, 1, 1)           # y: 64*192*256*512*4 B = 6.4 GB
+    ok = H.make_conv_desc((32, 8, 128, 512), 192, 8, (3, 3), 1, 1, 1)            # the benchmark's first layer: 1.6 GB
+    assert H.hcq_pack_floats(ok, 2) > 0 and H.hcq_pack_floats(big, 2) == 0       # mode 2: the pooling first-layer kernel
+    ok1 = H.make_conv_desc((32, 192, 16, 512), 192, 8, (3, 3), 1, 1, 1)
+    big1_2d = H.make_conv_desc((256, 192, 32, 512), 192, 8, (3, 3), 1, 1, 1)     # 3.2 GB each way ... x2 batch: 6.4 GB
+    big2_2d = H.make_conv_desc((512, 192, 32, 512), 192, 8, (3, 3), 1, 1, 1)
+    for mode in (0, 1):
+        assert H.hcq_pack_floats(ok1, mode) > 0
+        assert H.hcq_pack_floats(big2_2d, mode) == 0
+    del big1_2d
+    big1 = H.make_conv_desc((32, 192, 16384), 384, 8, (3,), 1, 1, 1)             # 1-D: y = 32*384*16384*4 B = 805 MB per ... ok
+    assert H.hcq_pack_floats(big1, 0) > 0
+    huge1 = H.make_conv_desc((256, 192, 16384), 384, 8, (3,), 1, 1, 1)           # y = 6.4 GB
+    assert H.hcq_pack_floats(huge1, 0) == 0 and H.hcq_pack_floats(huge1, 1) == 0
+    # grouped weight gradient: one image of either operand stays below 2 GB, the step space below 2^30
+    fam = L.lib().seld_hcq_wgrad_group_family
+    assert fam(ctypes.byref(H.make_conv_desc((32, 192, 512), 384, 8, (3,), 1, 1, 1))) == 0
+    assert fam(ctypes.byref(H.make_conv_desc((32, 192, 16, 512), 192, 8, (3, 3), 1, 1, 1))) == 2
+    assert fam(ctypes.byref(H.make_conv_desc((1, 192, 4096, 1024), 192, 8, (3, 3), 1, 1, 1))) == -1      # 3.2 GB per image
