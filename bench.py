@@ -54,7 +54,7 @@ PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense
 # cnn.0 forward, the one HBM-bound DualQ-Conv: the fast-product kernel with 1 or 2 block channels per K chunk
 # (only the networks' first layers have so few), or the block-matrix short-K kernel when that path is forced
-FIRST_LAYER_KERNELS = ("hcq_first_pool_kernel", "hcq_first_kernel", "hcq_conv_kernel<3, 3, 1,", "hcq_conv_kernel<3, 3, 2,", "hc_conv_smallk_kernel")
+FIRST_LAYER_KERNELS = ("first_stage_fwd", "hcq_first_pool_kernel", "hcq_first_kernel", "hcq_conv_kernel<3, 3, 1,", "hcq_conv_kernel<3, 3, 2,", "hc_conv_smallk_kernel")
 
 
 def first_layer_label(labels):

@@ -627,7 +627,9 @@ struct HcqPoolP {
     unsigned char* idx;          // same shape: that row (0..7)
 };
 
-template <int IBC, int NT1, int NT2, int NR, int R>
+// WY = false: y is not written and no statistics are gathered (csrc/first_stage.hip: the statistics come from the input's
+// second moments, the backward pass never reads y) -- the kernel's only output is the pooled-size window value + row.
+template <int IBC, int NT1, int NT2, int NR, int R, bool WY>
 __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, const HcqPoolP pp) {
     constexpr int KH = 3, KW = 3, TAPS = 9;
     constexpr int NT = NT1 + NT2;
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, co
     const float* const wbase = p.wpack;
     float* const dst = p.dst[0];
     const float* const bias = p.bias[0];
-    const bool want_stats = (p.epilogue[0] & SELD_EPI_STATS) != 0;
+    const bool want_stats = WY && (p.epilogue[0] & SELD_EPI_STATS) != 0;
     const int grp = fr >> 3;
     const unsigned img_off = (unsigned)n_img * (unsigned)p.Cdst * S;
     const unsigned PS = (unsigned)hblocks * (unsigned)p.W;                   // pooled plane
@@ -797,9 +799,11 @@ __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, co
                     const int chn = chb + q * p.OB;
                     float o[4] = {c[q][0], c[q][1], c[q][2], c[q][3]};
                     if (bias) { o[0] += bq[q]; o[1] += bq[q]; o[2] += bq[q]; o[3] += bq[q]; }
-                    *reinterpret_cast<float4*>(dst + img_off + (unsigned)chn * S + pos_off) = make_float4(o[0], o[1], o[2], o[3]);
-                    s1[q] += (o[0] + o[1]) + (o[2] + o[3]);
-                    s2[q] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                    if constexpr (WY) {
+                        *reinterpret_cast<float4*>(dst + img_off + (unsigned)chn * S + pos_off) = make_float4(o[0], o[1], o[2], o[3]);
+                        s1[q] += (o[0] + o[1]) + (o[2] + o[3]);
+                        s2[q] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         // first maximum wins, NaN propagates: "not (key <= best)" is true for a larger key and for NaN, and
@@ -1320,13 +1324,14 @@ extern "C" int seld_hcq_conv(const seld_conv_desc* d, int32_t mode, int32_t npai
 
 
 /* conv -> [BatchNorm2d -> ReLU ->] MaxPool2d(8, 1) for the network's first layer (model.py:273-281), pooling decision
- * inside the convolution (hcq_first_pool_kernel): writes y, the BatchNorm statistics (want_stats), and per pooling window
+ * inside the convolution (hcq_first_pool_kernel): writes y (nullable: not written, and then no statistics either -- the
+ * seld_first_stage_* path), the BatchNorm statistics (want_stats), and per pooling window
  * the raw value at the row that will be the maximum after BatchNorm + ReLU (by the sign of gamma) and that row.
  * wpack: seld_hcq_pack(desc, mode 2).  Follow with seld_bn_finalize_ex and seld_bn_pool_finish. */
 extern "C" int seld_hcq_first_pool(const seld_conv_desc* d, const float* x, const float* wpack, const float* bias,
                                    const float* gamma, int32_t want_stats, float* y, float* stats, float* pool_raw,
                                    uint8_t* idx, void* stream) {
-    if (hc_validate(d) != SELD_OK || !x || !wpack || !gamma || !y || !pool_raw || !idx || (want_stats && !stats)) return SELD_EINVAL;
+    if (hc_validate(d) != SELD_OK || !x || !wpack || !gamma || !pool_raw || !idx || (want_stats && (!stats || !y))) return SELD_EINVAL;
     HcqPlan pl = hcq_plan(d, 2, 1);
     HcqKern k;
     if (!pl.ok || !hcq_pick(pl, &k) || pl.first_rows != 8) return SELD_EUNSUPPORTED;
@@ -1340,7 +1345,7 @@ extern "C" int seld_hcq_first_pool(const seld_conv_desc* d, const float* x, cons
     hipStream_t st = (hipStream_t)stream;
 #define SELD_FP(IBC_, NT1_, NT2_, NR_)                                                                                  \
     do {                                                                                                                \
-        auto kern = hcq_first_pool_kernel<IBC_, NT1_, NT2_, NR_, 8>;                                                    \
+        auto kern = y ? hcq_first_pool_kernel<IBC_, NT1_, NT2_, NR_, 8, true> : hcq_first_pool_kernel<IBC_, NT1_, NT2_, NR_, 8, false>; \
         if (smem > 64 * 1024 &&                                                                                         \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return SELD_ELAUNCH;                                                                                        \

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void bn_pool_finish_kernel(const float* __rest
         if (v.y != v.y) o.y = v.y;
         if (v.z != v.z) o.z = v.z;
         if (v.w != v.w) o.w = v.w;
-        *reinterpret_cast<float4*>(pooled + base + s) = o;
+        if (pooled) *reinterpret_cast<float4*>(pooled + base + s) = o;
         if (out) {
             const uint4 r = philox4x32_10(offset + (uint64_t)((base + s) >> 2), seed);
             float4 d;
@@ -1087,7 +1087,7 @@ extern "C" int seld_dropout_fwd(const float* x, int64_t n, float p, uint64_t see
 extern "C" int seld_bn_pool_finish(const float* raw, int32_t N, int32_t C, int32_t S, const float* mean, const float* invstd,
                                    const float* gamma, const float* beta, float* pooled, float p, uint64_t seed,
                                    uint64_t offset, const uint64_t* state, float* out, void* stream) {
-    if (!raw || !mean || !invstd || !gamma || !beta || !pooled || N <= 0 || C <= 0 || S <= 0 || (S & 3)) return SELD_EINVAL;
+    if (!raw || !mean || !invstd || !gamma || !beta || (!pooled && !out) || N <= 0 || C <= 0 || S <= 0 || (S & 3)) return SELD_EINVAL;
     if (out && (p < 0.f || p >= 1.f)) return SELD_EINVAL;
     hipLaunchKernelGGL(bn_pool_finish_kernel, dim3((unsigned)(N * C)), dim3(256), 0, ST(stream), raw, C, S, mean, invstd,
                        gamma, beta, pooled, p, out ? 1.0f / (1.0f - p) : 1.0f, seed, offset, state, out);

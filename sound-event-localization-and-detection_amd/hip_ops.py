@@ -763,6 +763,7 @@ def run_branches(fa, xa, fb, xb):
 
 def _drop_kernel_choice_caches():
     hcq_weights.reset()
+    _fs_cache.clear()
     _hcq_labels.clear()
     _label_cache.clear()
     _pair_ok_cache.clear()
@@ -1801,6 +1802,49 @@ class ConvBnReluPoolFn(torch.autograd.Function):
         x = _req(x, "x")
         stats = new_stats(desc.Cout, x.device) if training else None
         wp = hcq_weights.get(desc, 2, ws) if (ph == 8 and algebra > 1) else None
+        ctx.gram = None
+        if wp is not None and training and _first_stage_nostore(desc):
+            # no convolution output at all (csrc/first_stage.hip): BatchNorm's statistics from the input's second moments,
+            # the pooling convolution writes the window value + row only, the backward pass works from those and x
+            lib = L.lib()
+            o = conv_out_shape(desc)
+            N, C, Hh, Ww = _y_shape(desc, o)
+            stage_timer = _Timed(desc, 0, label="first_stage_fwd(gram+bn+pool_conv+finish)" if kernel_timer.active else None)
+            stage_timer.__enter__()
+            gws = torch.empty(_fs_bytes(desc, "gram"), device=x.device, dtype=torch.uint8)
+            L.check(lib.seld_first_stage_gram(ctypes.byref(desc), L.ptr(x), L.ptr(gws), ctypes.c_size_t(gws.numel()),
+                                              L.current_stream()), "seld_first_stage_gram")
+            mean = torch.empty(C, device=x.device, dtype=torch.float32)
+            invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+            wg = torch.empty((C, 72), device=x.device, dtype=torch.float32)
+            L.check(lib.seld_first_stage_bn(ctypes.byref(desc), L.ptr_array8([_req(w, "w") for w in ws]), L.ptr(_req(bias, "bias")),
+                                            L.ptr(gws), ctypes.c_float(eps), ctypes.c_float(momentum), L.ptr(mean),
+                                            L.ptr(invstd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), L.ptr(wg),
+                                            L.current_stream()), "seld_first_stage_bn")
+            raw = torch.empty((N, C, Hh // ph, Ww), device=x.device, dtype=torch.float32)
+            idx = torch.empty(raw.shape, device=x.device, dtype=torch.uint8)
+            L.check(lib.seld_hcq_first_pool(ctypes.byref(desc), L.ptr(x), L.ptr(wp), L.ptr(_req(bias, "bias")),
+                                            L.ptr(gamma), 0, None, None, L.ptr(raw), L.ptr(idx), L.current_stream()),
+                    "seld_hcq_first_pool")
+            p_, seed, off, state = 0.0, 0, 0, None
+            pooled, out = None, None
+            if drop_p > 0.0:
+                p_ = float(drop_p)
+                seed, off, state = philox.draw((raw.numel() + 3) // 4, x.device)
+                out = torch.empty_like(raw)
+                ctx.rng = (p_, seed, off, state)
+            else:
+                pooled = torch.empty_like(raw)
+            L.check(lib.seld_bn_pool_finish(L.ptr(raw), N, C, (Hh // ph) * Ww, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                            L.ptr(beta), L.ptr(pooled), ctypes.c_float(p_), ctypes.c_uint64(seed),
+                                            ctypes.c_uint64(off), L.ptr(state), L.ptr(out), L.current_stream()),
+                    "seld_bn_pool_finish")
+            stage_timer.__exit__(None, None, None)
+            ctx.desc, ctx.geom = desc, (N, C, Hh, Ww, ph, training)
+            ctx.params = (ws, bias, gamma, beta)
+            ctx.gram = (gws, wg)
+            ctx.save_for_backward(x, raw, idx, mean, invstd)
+            return pooled if out is None else out
         if wp is not None:
             # the convolution picks every pooling window's element itself (by the sign of gamma): y is written for the
             # backward pass but never read back in the forward pass (csrc/hcq_conv.hip hcq_first_pool_kernel)
@@ -1850,6 +1894,8 @@ class ConvBnReluPoolFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpooled):
+        if ctx.gram is not None:
+            return ConvBnReluPoolFn._backward_nostore(ctx, dpooled)
         x, y, pooled, idx, mean, invstd = ctx.saved_tensors
         ws, bias, gamma, beta = ctx.params
         N, C, Hh, Ww, ph, training = ctx.geom
@@ -1879,6 +1925,56 @@ class ConvBnReluPoolFn(torch.autograd.Function):
         elif not clean:
             axpy_(slot, red, 2 * C)
         return (None, None, dg, db) + (None,) * (11 + len(ws))
+
+
+    @staticmethod
+    def _backward_nostore(ctx, dout):
+        x, raw, idx, mean, invstd = ctx.saved_tensors
+        ws, bias, gamma, beta = ctx.params
+        gws, wg = ctx.gram
+        N, C, Hh, Ww, ph, training = ctx.geom
+        dout = _req(dout, "dout")
+        p_, seed, off, state = ctx.rng if ctx.rng is not None else (0.0, 0, 0, None)
+        direct = _direct_targets(ws, bias)
+        if direct is None:
+            raise L.SeldHipError("ConvBnReluPoolFn needs gradient slots (FlatAdam); use hyper_conv_stats + bn_relu_pool")
+        slot, _ = _claim_grad_slots((gamma, beta))
+        red = slot if slot is not None else torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+        nbytes = _fs_bytes(ctx.desc, "bwd")
+        wsb = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        with _Timed(ctx.desc, 2, 1, label="fs_wgrad_kernel" if kernel_timer.active else None):
+            L.check(L.lib().seld_first_stage_bwd(ctypes.byref(ctx.desc), L.ptr(x), L.ptr(dout), L.ptr(raw), L.ptr(idx), L.ptr(mean),
+                                                 L.ptr(invstd), L.ptr(gamma), L.ptr(beta), L.ptr(bias), L.ptr(gws), L.ptr(wg),
+                                                 L.ptr(red), ctypes.c_void_p(red.data_ptr() + 4 * C), L.ptr_array8(direct[0]),
+                                                 ctypes.c_float(p_), ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(state),
+                                                 L.ptr(wsb), ctypes.c_size_t(nbytes), L.current_stream()),
+                    "seld_first_stage_bwd")
+        dg = db = None
+        if slot is None:
+            dg, db = red[:C], red[C:]
+        return (None, None, dg, db) + (None,) * (11 + len(ws))
+
+
+_fs_cache = {}
+
+
+def _fs_bytes(desc, which):
+    """Scratch bytes of the no-output first stage (csrc/first_stage.hip) for `desc`: which = 'gram' | 'bwd'; 0 = not taken."""
+    key = (bytes(desc), which)
+    v = _fs_cache.get(key)
+    if v is None:
+        lib = L.lib()
+        fn = lib.seld_first_stage_gram_workspace if which == "gram" else lib.seld_first_stage_bwd_workspace
+        fn.restype = ctypes.c_size_t
+        v = _fs_cache[key] = int(fn(ctypes.byref(desc)))
+    return v
+
+
+def _first_stage_nostore(desc):
+    """The first stage without its convolution output: 8 real input channels, shapes first_stage.hip takes (forward AND
+    backward), SELD_FIRST_STAGE_STORE_Y=1 restores the path that writes y."""
+    return (desc.Cin == 8 and not os.environ.get("SELD_FIRST_STAGE_STORE_Y") and _fs_bytes(desc, "gram") > 0 and
+            _fs_bytes(desc, "bwd") > 0)
 
 
 def conv_bn_relu_pool(x, ws, bias, bn, ph, pw, stride, padding, dilation, drop_p=0.0):

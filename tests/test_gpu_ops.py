@@ -641,3 +641,68 @@ def test_dataset_normalisation_full_size_properties():
     print(f"N1 48 clips: unit norm {ev[0].elapsed_time(ev[1]):.3f} ms, standardise {ev[1].elapsed_time(ev[2]):.3f} ms on the "
           f"device; host expressions {t_unit * 12e3:.0f} ms / {t_std * 12e3:.0f} ms (scaled from 4 clips, "
           f"{torch.get_num_threads()} threads)")
+
+
+def test_first_stage_full_size_without_conv_output(monkeypatch):
+    """The benchmark's first stage, (32, 8, 128, 512) -> 192 channels, training mode with Dropout: the path that never
+    writes the convolution output (csrc/first_stage.hip: statistics from the input's second moments, window value + row
+    from the pooling convolution, backward from the pooled-size tensors) against the path that writes y
+    (SELD_FIRST_STAGE_STORE_Y=1) -- outputs, running statistics, BatchNorm and convolution weight gradients -- and samples
+    0 and 31 of the output against the fp64 oracle with the batch statistics of the no-output path.  All 32-bit indexing of
+    the full-size tensors is in play here (1.6 GB of y on the comparison path).  Also: two runs of the no-output path give
+    bit-identical gradients (no atomics)."""
+    P = pkg()
+    H, T = P.hip_ops, P.train
+    gen = torch.Generator().manual_seed(29)
+    N, cout, hw, ph = 32, 192, (128, 512), 8
+    x = torch.randn(N, 8, *hw, generator=gen)
+    ws0 = [torch.randn(cout // 8, 1, 3, 3, generator=gen) * 0.3 for _ in range(8)]
+    g0, be0 = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.2
+    g0[1::5] *= -1.0
+    cot = torch.randn(N, cout, hw[0] // ph, hw[1], generator=gen)
+    xd, cotd = x.to(DEV), cot.to(DEV)
+
+    def run(store_y):
+        if store_y:
+            monkeypatch.setenv("SELD_FIRST_STAGE_STORE_Y", "1")
+        else:
+            monkeypatch.delenv("SELD_FIRST_STAGE_STORE_Y", raising=False)
+        ws = [torch.nn.Parameter(w.clone().to(DEV)) for w in ws0]
+        bn = P.hip_nn.BatchNorm2d(cout).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(g0.to(DEV)); bn.bias.copy_(be0.to(DEV))
+        opt = T.FlatAdam(ws + list(bn.parameters()), lr=1e-3)
+        opt.zero_grad()
+        H.philox.set_offset(4000)
+        y = H.conv_bn_relu_pool(xd, ws, None, bn, ph, 1, 1, 1, 1, drop_p=0.3)
+        (y * cotd).sum().backward()
+        torch.cuda.synchronize()
+        return (y.detach(), [w.grad.detach().clone() for w in ws], bn.weight.grad.clone(), bn.bias.grad.clone(),
+                bn.running_mean.clone(), bn.running_var.clone())
+
+    new, new2, old = run(False), run(False), run(True)
+    for a, b in zip(new[1] + [new[2], new[3]], new2[1] + [new2[2], new2[3]]):
+        assert torch.equal(a, b), "the no-output path is not reproducible"
+    assert torch.equal(new[0] == 0, old[0] == 0) or float(((new[0] == 0) != (old[0] == 0)).float().mean()) < 1e-5
+    _close(new[0].cpu(), old[0].cpu(), rel=1e-5, what="stage output")
+    _close(new[4].cpu(), old[4].cpu(), rel=1e-5, what="running_mean")
+    assert torch.allclose(new[5], old[5], rtol=1e-5), "running_var"
+    for a, b in zip(new[1], old[1]):
+        _close(a.cpu(), b.cpu(), rel=3e-4, what="conv weight gradient")
+    _close(new[2].cpu(), old[2].cpu(), rel=1e-4, what="dgamma")
+    _close(new[3].cpu(), old[3].cpu(), rel=1e-4, what="dbeta")
+    # fp64 oracle on samples 0 and 31: y = conv(x), z = relu(a y + b) with the batch statistics implied by the running buffers
+    mom = 0.1
+    mean = (new[4].cpu().double() - 0.0 * (1 - mom)) / mom                     # running_mean started at 0
+    cnt = N * hw[0] * hw[1]
+    var = ((new[5].cpu().double() - (1 - mom)) / mom) * (cnt - 1) / cnt        # running_var started at 1
+    a = g0.double() / torch.sqrt(var + 1e-5)
+    b = be0.double() - mean * a
+    for n in (0, 31):
+        yr = O.hypercomplex_conv(x[n:n + 1].double(), [w.double() for w in ws0], None, 1, 1, 1, 1, mode="explicit")
+        zr = F.max_pool2d(F.relu(yr * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)), (ph, 1))
+        got = new[0][n:n + 1].cpu().double()
+        kept = got != 0
+        assert 0.3 < float(kept.float().mean()) < 0.8
+        err = ((got * 0.7 - zr) * kept).abs().max()                            # kept elements carry z / (1 - p)
+        assert float(err) <= 2e-4 * float(zr.abs().max()), (n, float(err))
