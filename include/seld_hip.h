@@ -302,7 +302,7 @@ int seld_hcq_first_pool(const seld_conv_desc* desc, const float* x, const float*
  *   forward : seld_first_stage_gram -> seld_first_stage_bn (mean, invstd, running statistics, W G) ->
  *             seld_hcq_first_pool with y = NULL (window value + row) -> seld_bn_pool_finish
  *   backward: seld_first_stage_bwd (dgamma, dbeta, component weight gradients; reproducible: no atomics)
- * Shapes: Cin = 8, 3x3 'same' stride 1, H % 8 == 0, W % 64 == 0 (backward: Cout in {64, 128, 192}); workspace queries
+ * Shapes: Cin = 8, 3x3 'same' stride 1, H % 8 == 0, W % 64 == 0 (backward: Cout in {64, 128, 192}; 64 only for algebra 1 / 4); workspace queries
  * return 0 otherwise. */
 size_t seld_first_stage_gram_workspace(const seld_conv_desc* desc);
 int seld_first_stage_gram(const seld_conv_desc* desc, const float* x, void* workspace, size_t workspace_bytes, void* stream);
@@ -310,11 +310,10 @@ int seld_first_stage_bn(const seld_conv_desc* desc, const float* const w[8], con
                         float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float* wg /* (Cout, 72) or NULL */, void* stream);
 size_t seld_first_stage_bwd_workspace(const seld_conv_desc* desc);
-int seld_first_stage_bwd(const seld_conv_desc* desc, const float* x, const float* dout, const float* raw, const uint8_t* idx,
-                         const float* mean, const float* invstd, const float* gamma, const float* beta, const float* bias,
-                         const double* gram, const float* wg, float* dgamma, float* dbeta, float* const dw[8], float drop_p,
-                         uint64_t seed, uint64_t offset, const uint64_t* state, void* workspace, size_t workspace_bytes,
-                         void* stream);
+int seld_first_stage_bwd(const seld_conv_desc* desc, const float* x, const float* dout, const float* out, const float* raw,
+                         const uint8_t* idx, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                         const float* bias, const double* gram, const float* wg, float* dgamma, float* dbeta,
+                         float* const dw[8], float drop_p, void* workspace, size_t workspace_bytes, void* stream);
 
 int seld_bn_pool_finish(const float* raw, int32_t N, int32_t C, int32_t S /* pooled H * W */, const float* mean,
                         const float* invstd, const float* gamma, const float* beta, float* pooled, float p, uint64_t seed,

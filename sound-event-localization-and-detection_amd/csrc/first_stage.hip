@@ -128,8 +128,22 @@ __global__ __launch_bounds__(256, 2) void fs_gram_kernel(const FsGramP p) {
     }
 }
 
-// gram[i][j], 0 <= i, j < 80 (double, symmetric; row / column 72 = s, [72][72] = position count): partials added in order
-__global__ __launch_bounds__(256) void fs_gram_fold_kernel(const float* __restrict__ part, int nparts, double* __restrict__ gram) {
+// Ordered sum of `nparts` partial buffers of `n` floats each: red[e] = sum_w part[w][e] in double.  One workgroup per 64
+// consecutive elements; its four waves take the partials w = wave, wave + 4, ... (coalesced 256-byte reads) and their four
+// sums are added in wave order: the same order on every run.
+__global__ __launch_bounds__(256) void fs_sum_parts_kernel(const float* __restrict__ part, int nparts, int n, double* __restrict__ red) {
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    double a = 0.0;
+    if (e < n)
+        for (int w = wave; w < nparts; w += 4) a += (double)part[(size_t)w * n + e];
+    sh[wave][lane] = a;
+    __syncthreads();
+    if (wave == 0 && e < n) red[e] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+}
+// gram[i][j], 0 <= i, j < 80 (double, symmetric; row / column 72 = s, [72][72] = position count) from the summed tiles
+__global__ __launch_bounds__(256) void fs_gram_fold_kernel(const double* __restrict__ tiles, double* __restrict__ gram) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= FS_KP * FS_KP) return;
     const int i = e / FS_KP, j = e - i * FS_KP;
@@ -139,10 +153,7 @@ __global__ __launch_bounds__(256) void fs_gram_fold_kernel(const float* __restri
     if (t == u) { row = i & 15; col = j & 15; }                  // diagonal tile holds the full 16 x 16 block
     else { row = lo & 15; col = hi & 15; }
     const int ln = (row >> 2) * 16 + col;
-    const size_t off = (size_t)fs_tri(t, u) * 256 + ln * 4 + (row & 3);
-    double a = 0.0;
-    for (int w = 0; w < nparts; ++w) a += (double)part[(size_t)w * FS_NTILE * 256 + off];
-    gram[e] = a;
+    gram[e] = tiles[(size_t)fs_tri(t, u) * 256 + ln * 4 + (row & 3)];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -216,10 +227,13 @@ __global__ __launch_bounds__(256) void fs_bn_from_gram_kernel(const FsBnP p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward: per-channel reductions over the pooled-size tensors, reproducible (chunk partials + ordered sum)
-//   dz = dout * dropout mask * [a raw + b > 0]      xhat = (raw - mean) invstd       v0 = sum dz xhat, v1 = sum dz
+//   dz = dout * scale * [out != 0]      xhat = (raw - mean) invstd       v0 = sum dz xhat, v1 = sum dz
+// (out = relu(a raw + b) * mask * scale is non-zero exactly where ReLU is open AND the Dropout kept the element: the
+// stage's own output replays both decisions, no random numbers are redrawn)
 // ---------------------------------------------------------------------------------------------------------------------
 struct FsRedP {
     const float* dout;          // (N, C, PH, W): gradient w.r.t. the stage's output (behind the Dropout)
+    const float* out;           // (N, C, PH, W): the stage's output, relu(a raw + b) * dropout mask * scale
     const float* raw;           // (N, C, PH, W): convolution output at the window's chosen row
     const float* mean;
     const float* invstd;
@@ -228,34 +242,30 @@ struct FsRedP {
     float* part;                // [C][nchunk][2]
     int N, C, S;                // S = PH * W
     int nchunk;
-    DropP drop;
+    float scale;                // 1 / (1 - p) of the stage's Dropout (1: none)
 };
 __global__ __launch_bounds__(256) void fs_reduce_kernel(const FsRedP p) {
     const int c = blockIdx.y, chunk = blockIdx.x;
     const float mu = p.mean[c], is = p.invstd[c];
-    const float a = p.gamma[c] * is, b = p.beta[c] - mu * a;
     const long long total = (long long)p.N * p.S;                 // elements of this channel, S % 4 == 0
     const long long per = ((total / 4 + p.nchunk - 1) / p.nchunk) * 4;
     const long long beg = (long long)chunk * per;
     long long end = beg + per;
     if (end > total) end = total;
-    const uint64_t drop_off = p.drop.p > 0.f ? p.drop.offset + (p.drop.state ? p.drop.state[0] : 0) : 0;
     float v0 = 0.f, v1 = 0.f;
     for (long long k = beg + threadIdx.x * 4; k < end; k += 256 * 4) {
         const long long n = k / p.S;
         const size_t off = ((size_t)n * p.C + c) * p.S + (size_t)(k - n * p.S);
         const float4 r4 = *reinterpret_cast<const float4*>(p.raw + off);
-        float4 d4 = *reinterpret_cast<const float4*>(p.dout + off);
-        if (p.drop.p > 0.f) {
-            const float4 mk = dropout_mask4(drop_off + (uint64_t)(off >> 2), p.drop.seed, p.drop.p, p.drop.scale);
-            d4.x *= mk.x; d4.y *= mk.y; d4.z *= mk.z; d4.w *= mk.w;
-        }
-        const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float4 d4 = *reinterpret_cast<const float4*>(p.dout + off);
+        const float4 o4 = *reinterpret_cast<const float4*>(p.out + off);
+        const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w}, oo[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (rr[e] * a + b > 0.f) {
-                v0 += dd[e] * ((rr[e] - mu) * is);
-                v1 += dd[e];
+            if (oo[e] != 0.f) {
+                const float dz = dd[e] * p.scale;
+                v0 += dz * ((rr[e] - mu) * is);
+                v1 += dz;
             }
     }
     __shared__ float r0[4], r1[4];
@@ -291,32 +301,37 @@ __global__ void fs_coef_kernel(const float* __restrict__ part, int nchunk, const
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward: sum_pos (a dz)(pos) xcol(pos)^T on the matrix cores -- rows = output channels, columns = the 72 (+8) xcol rows.
-// A workgroup walks blocks of 8 window rows x 64 columns; wave w owns channel tiles w, w + 4, w + 8 (all positions of the
-// block), so that with the dual quaternion's primal / dual halves every wave has 11 or 13 of the 48 tiles per k-step
-// (primal channels do not see the dual input: column tiles 3, 4 are skipped for them).  The A operand of row r of a
-// window is the pooled-size value masked by (arg-max row == r): loaded once per 4 columns, used for 8 rows.
+// A workgroup (8 waves) walks blocks of 8 window rows x 64 columns.  Wave (hc, cq) owns HALF of the channel tiles
+// (hc: for the dual quaternion half of the primal tiles + half of the dual ones, so both halves issue the same number of
+// MFMAs -- primal channels do not see the dual input: column tiles 3, 4 are skipped for them) and a QUARTER of the columns
+// (cq): a k-step of 4 positions is 5 LDS reads of xcol for 24 MFMAs (with every wave on all positions and a sixth of the
+// channels it was 5 reads per 12 and LDS-bound on bank conflicts: 695 us, r3l).  The A operand of window row r is the
+// pooled-size value masked by (arg-max row == r): loaded once per 4 columns, one group ahead, used for 8 rows.
 // ---------------------------------------------------------------------------------------------------------------------
 struct FsWgP {
     const float* x;
     const float* dout;
-    const float* raw;
+    const float* out;           // the stage's output: non-zero where ReLU is open and the Dropout kept the element
     const unsigned char* idx;
-    const float* mean;
     const float* invstd;
     const float* gamma;
-    const float* beta;
     float* part;                // [nwg][ctiles][5][256]
     int N, C, H, W;
     int nblocks;
-    int half_tiles;             // dual quaternion: channel tiles below this hold primal channels (3 column tiles); else 0
-    DropP drop;
+    float scale;                // 1 / (1 - p)
 };
 
-template <int TPW>
-__global__ __launch_bounds__(256, 2) void fs_wgrad_kernel(const FsWgP p) {
-    __shared__ __attribute__((aligned(16))) float lds[8 * FS_XR * FS_WEXT];
+// NTW channel tiles per wave (C / 32); DQ: the first NTW / 2 of them are primal (narrow)
+template <int NTW, bool DQ>
+__global__ __launch_bounds__(512, 2) void fs_wgrad_kernel(const FsWgP p) {
+    constexpr int NARROW = DQ ? NTW / 2 : 0;
+    constexpr int NACC = NARROW * 3 + (NTW - NARROW) * 5;
+    constexpr int XT = 8 * FS_XR * FS_WEXT;
+    constexpr int RED = 2 * NACC * 256;                       // one reduction round: both channel halves
+    __shared__ __attribute__((aligned(16))) float lds[(2 * XT > RED ? 2 * XT : RED) + 192];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hc = wave >> 2, cq = wave & 3;
     const int fr = lane & 15, fk = lane >> 4;
     int goff[5];
     bool gld[5];
@@ -325,107 +340,163 @@ __global__ __launch_bounds__(256, 2) void fs_wgrad_kernel(const FsWgP p) {
         const int kk = 16 * t + fr;
         const int kc = kk < FS_K ? kk : 0;
         const int ch = kc / 9, tap = kc - ch * 9, kh = tap / 3, kw = tap - kh * 3;
-        goff[t] = (ch * FS_XR + kh) * FS_WEXT + FS_DPAD + fk + (kw - 1);
+        goff[t] = (ch * FS_XR + kh) * FS_WEXT + FS_DPAD + 16 * cq + fk + (kw - 1);
         gld[t] = kk < FS_K;
     }
-    // this wave's channel tiles and the lane's channel constants
-    int chn[TPW];
-    float ca[TPW], cb[TPW];
-    bool narrow[TPW];           // primal channels of a dual quaternion: column tiles 0..2 only
+    // this wave's channel tiles (tile index in [0, C / 16), wave-uniform); a = gamma invstd (times the Dropout's scale) of
+    // every channel in LDS, behind the two x tiles
+    auto ctile = [&](int i) __attribute__((always_inline)) -> int {
+        if (DQ) return i < NARROW ? hc * NARROW + i : NTW + hc * NARROW + (i - NARROW);          // NTW = C / 32 = primal tiles
+        return hc * NTW + i;
+    };
+    float* const ab = lds + 2 * XT;
+    for (int c = tid; c < p.C; c += 512) ab[c] = p.gamma[c] * p.invstd[c] * p.scale;
+    auto acc_idx = [](int i, int u) constexpr { return i < NARROW ? i * 3 + u : NARROW * 3 + (i - NARROW) * 5 + u; };
+    floatx4 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int ct = wave + 4 * i;
-        chn[i] = ct * 16 + fr;
-        const float is = p.invstd[chn[i]], mu = p.mean[chn[i]];
-        ca[i] = p.gamma[chn[i]] * is;
-        cb[i] = p.beta[chn[i]] - mu * ca[i];
-        narrow[i] = ct < p.half_tiles;
-    }
-    floatx4 acc[TPW][5];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int u = 0; u < 5; ++u) acc[i][u] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NACC; ++i) acc[i] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
     const int wq = p.W >> 6, hq = p.H >> 3, PH = hq;
     const size_t PS = (size_t)PH * p.W;
-    const uint64_t drop_off = p.drop.p > 0.f ? p.drop.offset + (p.drop.state ? p.drop.state[0] : 0) : 0;
-    for (int b = blockIdx.x; b < p.nblocks; b += gridDim.x) {
+    // The x tile of the NEXT block is fetched into registers while this block is multiplied and written to the other LDS
+    // buffer at the end (one workgroup per CU at this register count: nobody else would cover a tile's memory latency).
+    constexpr int QW = FS_WEXT / 4, NQ = 8 * FS_XR * QW, NST = (NQ + 511) / 512;
+    float4 stage[NST];
+    auto fetch_tile = [&](int b) __attribute__((always_inline)) {
         const int n = b / (hq * wq), rem = b - n * (hq * wq);
-        const int q = rem / wq, h0 = q * 8, w0 = (rem % wq) * 64;
-        __syncthreads();
-        fs_stage_x(p.x, lds, n, h0, w0, p.H, p.W, tid);
-        __syncthreads();
-        // pooled-size operands of 4-column group jg: lane (fr, fk) = (channel, column); one group ahead in registers
-        float vz[2][TPW];
-        int ri[2][TPW];
-        auto load_group = [&](int jg, int slot) __attribute__((always_inline)) {
+        const int h0 = (rem / wq) * 8, w0 = (rem % wq) * 64;
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const size_t off = ((size_t)n * p.C + chn[i]) * PS + (size_t)q * p.W + (size_t)(w0 + 4 * jg + fk);
-                const float rw = p.raw[off];
-                float d = p.dout[off];
-                if (p.drop.p > 0.f) {
-                    const float4 mk = dropout_mask4(drop_off + (uint64_t)(off >> 2), p.drop.seed, p.drop.p, p.drop.scale);
-                    const float m4[4] = {mk.x, mk.y, mk.z, mk.w};
-                    d *= m4[off & 3];
+        for (int k = 0; k < NST; ++k) {
+            const int f = tid + 512 * k;
+            const int row = f / QW, quad = f - row * QW;
+            const int ch = row / FS_XR, xr = row - ch * FS_XR;
+            const int hh = h0 - 1 + xr, ww = w0 - FS_DPAD + 4 * quad;
+            stage[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < NQ && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W)
+                stage[k] = *reinterpret_cast<const float4*>(p.x + (((size_t)n * 8 + ch) * p.H + hh) * p.W + ww);
+        }
+    };
+    auto store_tile = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int f = tid + 512 * k;
+            if (f < NQ) *reinterpret_cast<float4*>(buf + f * 4) = stage[k];
+        }
+    };
+    // pooled-size operands of 4-column group jg of this wave's 16 columns in block b: lane (fr, fk) = (channel, column).
+    // Always one group AHEAD in registers -- across block boundaries too: a group's 3 * NTW loads come from HBM (the
+    // pooled-size tensors are 0.45 GB) and need a whole group's MFMAs (2.6 us) to land.
+    // (the loads of the NEXT group are issued -- all 3 * NTW unconditionally, no select that would make one wait for another
+    // -- before this group's MFMAs and turned into operands after them: r3o's version waited for memory tile by tile)
+    float vz[NTW];
+    unsigned rpk = 0;                                             // the NTW arg-max rows of the current group, 3 bits each
+    float ld_o[NTW], ld_d[NTW];
+    unsigned ld_i[NTW];
+    auto issue_group = [&](int b, int jg) __attribute__((always_inline)) {
+        const int n = b / (hq * wq), rem = b - n * (hq * wq);
+        const int q = rem / wq, w0 = (rem % wq) * 64;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int chn = ctile(i) * 16 + fr;
+            const size_t off = ((size_t)n * p.C + chn) * PS + (size_t)q * p.W + (size_t)(w0 + 16 * cq + 4 * jg + fk);
+            ld_o[i] = p.out[off];
+            ld_d[i] = p.dout[off];
+            ld_i[i] = p.idx[off];
+        }
+    };
+    auto finish_group = [&]() __attribute__((always_inline)) {
+        unsigned pk = 0;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const float a_ = ab[ctile(i) * 16 + fr];
+            vz[i] = ld_o[i] != 0.f ? ld_d[i] * a_ : 0.f;
+            pk |= (ld_i[i] & 7u) << (3 * i);
+        }
+        rpk = pk;
+    };
+    int bufsel = 0;
+    if ((int)blockIdx.x < p.nblocks) { fetch_tile(blockIdx.x); store_tile(lds); }
+    __syncthreads();                                              // (also: the a-table `ab` is complete)
+    if ((int)blockIdx.x < p.nblocks) issue_group(blockIdx.x, 0);
+    for (int b = blockIdx.x; b < p.nblocks; b += gridDim.x) {
+        const float* xt = lds + bufsel * XT;
+        const bool more = b + (int)gridDim.x < p.nblocks;
+        if (more) fetch_tile(b + gridDim.x);
+        float bv[5], bn_[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) bv[u] = gld[u] ? xt[goff[u]] : 0.f;
+#pragma unroll
+        for (int jg = 0; jg < 4; ++jg) {
+            finish_group();
+            if (jg + 1 < 4) issue_group(b, jg + 1);
+            else if (more) issue_group(b + gridDim.x, 0);
+#pragma unroll 2
+            for (int r = 0; r < 8; ++r) {
+                // the xcol values of the NEXT k-step (next row; behind row 7: row 0 of the next column group) under this one's MFMAs
+                const int rn = r + 1 < 8 ? r + 1 : 0, jn = r + 1 < 8 ? jg : (jg + 1 < 4 ? jg + 1 : 0);
+#pragma unroll
+                for (int u = 0; u < 5; ++u) bn_[u] = gld[u] ? xt[goff[u] + rn * FS_WEXT + 4 * jn] : 0.f;
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    const float av = ((rpk >> (3 * i)) & 7u) == (unsigned)r ? vz[i] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < (i < NARROW ? 3 : 5); ++u)
+                        acc[acc_idx(i, u)] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[u], acc[acc_idx(i, u)], 0, 0, 0);
                 }
-                vz[slot][i] = (rw * ca[i] + cb[i] > 0.f) ? d * ca[i] : 0.f;
-                ri[slot][i] = p.idx[off];
-            }
-        };
-        load_group(0, 0);
-#pragma unroll 1
-        for (int jg = 0; jg < 16; jg += 2) {
 #pragma unroll
-            for (int par = 0; par < 2; ++par) {
-                if (jg + par + 1 < 16) load_group(jg + par + 1, par ^ 1);
-#pragma unroll 1
-                for (int r = 0; r < 8; ++r) {
-                    float bv[5], av[TPW];
-#pragma unroll
-                    for (int u = 0; u < 5; ++u) bv[u] = gld[u] ? lds[goff[u] + r * FS_WEXT + 4 * (jg + par)] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < TPW; ++i) av[i] = ri[par][i] == r ? vz[par][i] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < TPW; ++i) {
-#pragma unroll
-                        for (int u = 0; u < 3; ++u) acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[u], acc[i][u], 0, 0, 0);
-                        if (!narrow[i]) {
-#pragma unroll
-                            for (int u = 3; u < 5; ++u) acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[u], acc[i][u], 0, 0, 0);
-                        }
-                    }
-                }
+                for (int u = 0; u < 5; ++u) bv[u] = bn_[u];
             }
         }
+        if (more) store_tile(lds + (bufsel ^ 1) * XT);
+        bufsel ^= 1;
+        __syncthreads();
     }
-    float* out = p.part + (size_t)blockIdx.x * (4 * TPW) * 5 * 256 + lane * 4;
+    // ---- the four column-quarter waves of each channel half -> one partial per workgroup (quarters 1..3 through LDS, added
+    // by quarter 0 in order) ---------------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int k = 1; k < 4; ++k) {
+        __syncthreads();
+        if (cq == k) {
+            float* dst = lds + hc * NACC * 256 + lane * 4;
 #pragma unroll
-    for (int i = 0; i < TPW; ++i)
+            for (int i = 0; i < NACC; ++i) *reinterpret_cast<floatx4*>(dst + i * 256) = acc[i];
+        }
+        __syncthreads();
+        if (cq == 0) {
+            const float* src = lds + hc * NACC * 256 + lane * 4;
 #pragma unroll
-        for (int u = 0; u < 5; ++u) *reinterpret_cast<floatx4*>(out + ((wave + 4 * i) * 5 + u) * 256) = acc[i][u];
+            for (int i = 0; i < NACC; ++i) acc[i] += *reinterpret_cast<const floatx4*>(src + i * 256);
+        }
+    }
+    if (cq == 0) {
+        float* out = p.part + (size_t)blockIdx.x * (2 * NTW) * 5 * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                floatx4 v = (floatx4){0.f, 0.f, 0.f, 0.f};
+                if (u < (i < NARROW ? 3 : 5)) v = acc[acc_idx(i, u)];
+                *reinterpret_cast<floatx4*>(out + (ctile(i) * 5 + u) * 256) = v;
+            }
+    }
 }
 
-// dWf[c][kk] = sum over workgroups (in order) + c1_c (W G)[c][kk] + c0_c s[kk]
+// dWf[c][kk] = (workgroup partials, summed in order by fs_sum_parts_kernel) + c1_c (W G + bias s)[c][kk] + c0_c s[kk]
 struct FsWsumP {
-    const float* part;
+    const double* sum;          // [ctiles][5][256]
     const float* wg;            // (C, 72): W G
     const double* gram;
     const float* coef;          // [c1 | a | c0]
     const float* bias;          // nullable: the convolution's bias (y = W xcol + bias, so sum y xcol = W G + bias s)
     float* dwf;                 // (C, 72)
-    int C, nparts, ctiles;
+    int C;
 };
 __global__ __launch_bounds__(256) void fs_wsum_kernel(const FsWsumP p) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= p.C * FS_K) return;
     const int c = e / FS_K, kk = e - c * FS_K;
     const int ct = c >> 4, row = c & 15, u = kk >> 4, col = kk & 15;
-    const size_t off = ((size_t)ct * 5 + u) * 256 + ((row >> 2) * 16 + col) * 4 + (row & 3);
-    const size_t stride = (size_t)p.ctiles * 5 * 256;
-    double a = 0.0;
-    for (int w = 0; w < p.nparts; ++w) a += (double)p.part[(size_t)w * stride + off];
+    double a = p.sum[((size_t)ct * 5 + u) * 256 + ((row >> 2) * 16 + col) * 4 + (row & 3)];
     const double sk = p.gram[FS_K * FS_KP + kk];
     a += (double)p.coef[c] * ((double)p.wg[e] + (p.bias ? (double)p.bias[c] * sk : 0.0)) + (double)p.coef[2 * p.C + c] * sk;
     p.dwf[e] = (float)a;
@@ -472,11 +543,12 @@ static int fs_gram_wgs(const seld_conv_desc* d) {
 using namespace seld;
 
 /* Scratch bytes of seld_first_stage_gram (0: not a first layer this path takes: 8 real input channels, 3x3 'same',
- * H % 8 == 0, W % 64 == 0).  Layout: [80 x 80 doubles: G, s in row / column 72, the position count at [72][72]] then the
- * workgroups' partial tiles. */
+ * H % 8 == 0, W % 64 == 0).  Layout: [80 x 80 doubles: G, s in row / column 72, the position count at [72][72]] then
+ * internal scratch (summed tiles, the workgroups' partial tiles). */
 extern "C" size_t seld_first_stage_gram_workspace(const seld_conv_desc* d) {
     if (!fs_shape_ok(d)) return 0;
-    return (size_t)FS_KP * FS_KP * sizeof(double) + (size_t)fs_gram_wgs(d) * FS_NTILE * 256 * sizeof(float);
+    return (size_t)FS_KP * FS_KP * sizeof(double) + (size_t)FS_NTILE * 256 * sizeof(double) +
+           (size_t)fs_gram_wgs(d) * FS_NTILE * 256 * sizeof(float);
 }
 
 /* Second moments of the 3x3 neighbourhoods of x (N, 8, H, W): gram = first 80 x 80 doubles of `workspace`.  They depend on
@@ -491,13 +563,17 @@ extern "C" int seld_first_stage_gram(const seld_conv_desc* d, const float* x, vo
     p.x = x; p.N = d->N; p.H = d->in[0]; p.W = d->in[1];
     p.nblocks = d->N * (d->in[0] / 8) * (d->in[1] / 64);
     double* gram = (double*)workspace;
-    p.part = (float*)((char*)workspace + (size_t)FS_KP * FS_KP * sizeof(double));
+    double* tiles = gram + FS_KP * FS_KP;
+    p.part = (float*)(tiles + FS_NTILE * 256);
     const int nwg = fs_gram_wgs(d);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(fs_gram_kernel, dim3(nwg), dim3(256), 0, st, p);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(fs_gram_fold_kernel, dim3((FS_KP * FS_KP + 255) / 256), dim3(256), 0, st, p.part, nwg, gram);
+    hipLaunchKernelGGL(fs_sum_parts_kernel, dim3(FS_NTILE * 256 / 64), dim3(256), 0, st, p.part, nwg, FS_NTILE * 256, tiles);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(fs_gram_fold_kernel, dim3((FS_KP * FS_KP + 255) / 256), dim3(256), 0, st, tiles, gram);
     return check_launch();
 }
 
@@ -522,8 +598,9 @@ extern "C" int seld_first_stage_bn(const seld_conv_desc* d, const float* const w
 }
 
 static int fs_wg_count(const seld_conv_desc* d) {
+    // one 512-thread workgroup fits a CU at this kernel's register count: one per CU, each walking nblocks / 256 blocks
     const long long nblocks = (long long)d->N * (d->in[0] / 8) * (d->in[1] / 64);
-    return (int)(nblocks < 512 ? nblocks : 512);
+    return (int)(nblocks < 256 ? nblocks : 256);
 }
 static int fs_red_chunks(const seld_conv_desc* d) {
     const long long total = (long long)d->N * (d->in[0] / 8) * d->in[1];
@@ -536,23 +613,23 @@ static int fs_red_chunks(const seld_conv_desc* d) {
 /* Scratch bytes of seld_first_stage_bwd (0: shape not taken -- additionally Cout % 64 == 0 and Cout <= 192). */
 extern "C" size_t seld_first_stage_bwd_workspace(const seld_conv_desc* d) {
     if (!fs_shape_ok(d) || d->Cout % 64 || d->Cout > 192) return 0;
+    if (d->algebra != 8 && d->Cout != 64) return 0;               // wider real / quaternion first layers: not instantiated
     const int C = d->Cout;
     return (size_t)C * fs_red_chunks(d) * 2 * sizeof(float) + (size_t)3 * C * sizeof(float) + (size_t)C * FS_K * sizeof(float) +
-           (size_t)fs_wg_count(d) * (C / 16) * 5 * 256 * sizeof(float) + 64;
+           (size_t)(C / 16) * 5 * 256 * sizeof(double) + (size_t)fs_wg_count(d) * (C / 16) * 5 * 256 * sizeof(float) + 64;
 }
 
 /* Backward pass of the first stage (training mode, batch statistics) WITHOUT the convolution output:
- *   dout (N, Cout, H/8, W) gradient w.r.t. the stage's output, the stage's Dropout mask replayed (drop_p, seed, offset,
- *   state as in seld_dropout_fwd; drop_p = 0: none); raw / idx as written by seld_hcq_first_pool; mean / invstd from
+ *   dout (N, Cout, H/8, W) gradient w.r.t. the stage's output `out` (= relu(a raw + b) * Dropout mask / (1 - drop_p); its
+ *   zeros replay ReLU and the Dropout, drop_p = 0: none); raw / idx as written by seld_hcq_first_pool; mean / invstd from
  *   seld_first_stage_bn, wg = W G from there, gram from seld_first_stage_gram; bias: the convolution's (nullable).
  * Adds the BatchNorm weight / bias gradients to dgamma / dbeta and the convolution's component weight gradients to dw[c]
  * (torch autograd through model.py:273-283 in the reference).  No atomics: reproducible. */
-extern "C" int seld_first_stage_bwd(const seld_conv_desc* d, const float* x, const float* dout, const float* raw,
-                                    const uint8_t* idx, const float* mean, const float* invstd, const float* gamma,
+extern "C" int seld_first_stage_bwd(const seld_conv_desc* d, const float* x, const float* dout, const float* out,
+                                    const float* raw, const uint8_t* idx, const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, const float* bias, const double* gram, const float* wg, float* dgamma, float* dbeta,
-                                    float* const dw[8], float drop_p, uint64_t seed, uint64_t offset, const uint64_t* state,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
-    if (!d || !x || !dout || !raw || !idx || !mean || !invstd || !gamma || !beta || !gram || !wg || !dgamma || !dbeta || !dw ||
+                                    float* const dw[8], float drop_p, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !x || !dout || !out || !raw || !idx || !mean || !invstd || !gamma || !beta || !gram || !wg || !dgamma || !dbeta || !dw ||
         !workspace)
         return SELD_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f) return SELD_EINVAL;
@@ -564,14 +641,14 @@ extern "C" int seld_first_stage_bwd(const seld_conv_desc* d, const float* x, con
     float* red_part = (float*)workspace;
     float* coef = red_part + (size_t)C * nchunk * 2;
     float* dwf = coef + 3 * C;
-    float* part = dwf + (size_t)C * FS_K;
-    part = (float*)(((uintptr_t)part + 15) & ~(uintptr_t)15);
-    const DropP dr{drop_p, 1.0f / (1.0f - drop_p), seed, offset, state};
+    double* wsumd = (double*)(((uintptr_t)(dwf + (size_t)C * FS_K) + 15) & ~(uintptr_t)15);
+    float* part = (float*)(wsumd + (size_t)(C / 16) * 5 * 256);
+    const float scale = 1.0f / (1.0f - drop_p);
     hipStream_t st = (hipStream_t)stream;
 
     FsRedP rp{};
-    rp.dout = dout; rp.raw = raw; rp.mean = mean; rp.invstd = invstd; rp.gamma = gamma; rp.beta = beta; rp.part = red_part;
-    rp.N = d->N; rp.C = C; rp.S = PH * W; rp.nchunk = nchunk; rp.drop = dr;
+    rp.dout = dout; rp.out = out; rp.raw = raw; rp.mean = mean; rp.invstd = invstd; rp.gamma = gamma; rp.beta = beta; rp.part = red_part;
+    rp.N = d->N; rp.C = C; rp.S = PH * W; rp.nchunk = nchunk; rp.scale = scale;
     hipLaunchKernelGGL(fs_reduce_kernel, dim3(nchunk, C), dim3(256), 0, st, rp);
     int rc = check_launch();
     if (rc) return rc;
@@ -581,18 +658,22 @@ extern "C" int seld_first_stage_bwd(const seld_conv_desc* d, const float* x, con
     if (rc) return rc;
 
     FsWgP wp{};
-    wp.x = x; wp.dout = dout; wp.raw = raw; wp.idx = idx; wp.mean = mean; wp.invstd = invstd; wp.gamma = gamma; wp.beta = beta;
+    wp.x = x; wp.dout = dout; wp.out = out; wp.idx = idx; wp.invstd = invstd; wp.gamma = gamma;
     wp.part = part; wp.N = d->N; wp.C = C; wp.H = H; wp.W = W; wp.nblocks = d->N * PH * (W / 64);
-    wp.half_tiles = d->algebra == 8 ? C / 32 : 0;
-    wp.drop = dr;
-    if (C == 192) hipLaunchKernelGGL(fs_wgrad_kernel<3>, dim3(nwg), dim3(256), 0, st, wp);
-    else if (C == 128) hipLaunchKernelGGL(fs_wgrad_kernel<2>, dim3(nwg), dim3(256), 0, st, wp);
-    else hipLaunchKernelGGL(fs_wgrad_kernel<1>, dim3(nwg), dim3(256), 0, st, wp);
+    wp.scale = scale;
+    const bool dq = d->algebra == 8;
+    if (C == 192) hipLaunchKernelGGL((fs_wgrad_kernel<6, true>), dim3(nwg), dim3(512), 0, st, wp);
+    else if (C == 128) hipLaunchKernelGGL((fs_wgrad_kernel<4, true>), dim3(nwg), dim3(512), 0, st, wp);
+    else { if (dq) hipLaunchKernelGGL((fs_wgrad_kernel<2, true>), dim3(nwg), dim3(512), 0, st, wp); else hipLaunchKernelGGL((fs_wgrad_kernel<2, false>), dim3(nwg), dim3(512), 0, st, wp); }
+    rc = check_launch();
+    if (rc) return rc;
+    const int nsum = (C / 16) * 5 * 256;
+    hipLaunchKernelGGL(fs_sum_parts_kernel, dim3(nsum / 64), dim3(256), 0, st, part, nwg, nsum, wsumd);
     rc = check_launch();
     if (rc) return rc;
 
     FsWsumP sp{};
-    sp.part = part; sp.wg = wg; sp.gram = gram; sp.coef = coef; sp.bias = bias; sp.dwf = dwf; sp.C = C; sp.nparts = nwg; sp.ctiles = C / 16;
+    sp.sum = wsumd; sp.wg = wg; sp.gram = gram; sp.coef = coef; sp.bias = bias; sp.dwf = dwf; sp.C = C;
     hipLaunchKernelGGL(fs_wsum_kernel, dim3((C * FS_K + 255) / 256), dim3(256), 0, st, sp);
     rc = check_launch();
     if (rc) return rc;

@@ -1843,8 +1843,9 @@ class ConvBnReluPoolFn(torch.autograd.Function):
             ctx.desc, ctx.geom = desc, (N, C, Hh, Ww, ph, training)
             ctx.params = (ws, bias, gamma, beta)
             ctx.gram = (gws, wg)
-            ctx.save_for_backward(x, raw, idx, mean, invstd)
-            return pooled if out is None else out
+            result = pooled if out is None else out
+            ctx.save_for_backward(x, raw, idx, mean, invstd, result)      # the output's zeros replay ReLU + Dropout backward
+            return result
         if wp is not None:
             # the convolution picks every pooling window's element itself (by the sign of gamma): y is written for the
             # backward pass but never read back in the forward pass (csrc/hcq_conv.hip hcq_first_pool_kernel)
@@ -1929,7 +1930,7 @@ class ConvBnReluPoolFn(torch.autograd.Function):
 
     @staticmethod
     def _backward_nostore(ctx, dout):
-        x, raw, idx, mean, invstd = ctx.saved_tensors
+        x, raw, idx, mean, invstd, out = ctx.saved_tensors
         ws, bias, gamma, beta = ctx.params
         gws, wg = ctx.gram
         N, C, Hh, Ww, ph, training = ctx.geom
@@ -1943,11 +1944,11 @@ class ConvBnReluPoolFn(torch.autograd.Function):
         nbytes = _fs_bytes(ctx.desc, "bwd")
         wsb = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
         with _Timed(ctx.desc, 2, 1, label="fs_wgrad_kernel" if kernel_timer.active else None):
-            L.check(L.lib().seld_first_stage_bwd(ctypes.byref(ctx.desc), L.ptr(x), L.ptr(dout), L.ptr(raw), L.ptr(idx), L.ptr(mean),
-                                                 L.ptr(invstd), L.ptr(gamma), L.ptr(beta), L.ptr(bias), L.ptr(gws), L.ptr(wg),
-                                                 L.ptr(red), ctypes.c_void_p(red.data_ptr() + 4 * C), L.ptr_array8(direct[0]),
-                                                 ctypes.c_float(p_), ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(state),
-                                                 L.ptr(wsb), ctypes.c_size_t(nbytes), L.current_stream()),
+            L.check(L.lib().seld_first_stage_bwd(ctypes.byref(ctx.desc), L.ptr(x), L.ptr(dout), L.ptr(out), L.ptr(raw), L.ptr(idx),
+                                                 L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), L.ptr(bias), L.ptr(gws),
+                                                 L.ptr(wg), L.ptr(red), ctypes.c_void_p(red.data_ptr() + 4 * C),
+                                                 L.ptr_array8(direct[0]), ctypes.c_float(p_), L.ptr(wsb),
+                                                 ctypes.c_size_t(nbytes), L.current_stream()),
                     "seld_first_stage_bwd")
         dg = db = None
         if slot is None:

@@ -149,6 +149,10 @@ MODEL_CASES += [
 MODEL_CASES += [
     dict(_WIDE, name="c1w_train", domain="R", domain_classifier="R", input_channels=8, cnn_filters=[64, 64, 64], G=128,
          U=64, V=[128, 128], fc_layers=[128],
+         # torch's own fp32 CPU run of this case is 2.08 % of max|g| away from its fp64 run on ResBlocks.2.conv2_skip.weight
+         # (0.7-0.9 % on the other stored gradients): measured with the oracle in both precisions; the HIP path lands on the
+         # fp32 CPU value to four digits
+         grad_tol=4e-2,
          full_grads=["seld_block.cnn.0.0.weight", "seld_block.tcn.ResBlocks.6.conv1_gate.weight",
                      "seld_block.tcn.ResBlocks.2.conv2_skip.weight", "doa.0.weight"]),
 ]
