@@ -380,6 +380,18 @@ int seld_hcq_wgrad_row_label(const seld_conv_desc* desc, int32_t npair, char* bu
 int seld_hcq_wgrad_row_acc(const seld_conv_desc* desc, int32_t npair, const float* x, const float* dyA, const float* dyB,
                            float* const dwA[8], float* const dwB[8], void* workspace, size_t workspace_bytes, void* stream);
 
+/* SELD_DETERMINISTIC=1 (read with the other switches, seld_env_reload): reductions that are normally split over workgroups and
+ * folded with float atomics -- BatchNorm statistics (seld_channel_stats), the two-pass BatchNorm / gate / pooling backward
+ * reductions, linear-layer weight and bias gradients, the loss sum, the position splits of seld_hc_conv_bwd_weight* -- run as
+ * ONE ordered chain per output element.  The host mirror then also keeps statistics out of the convolution epilogues and
+ * takes the weight gradient below for every layer the grouped kernels do not take.
+ * seld_hc_conv_bwd_weight_det: reproducible dw[c] += weight gradient of any convolution (real / quaternion / dual quaternion:
+ * quaternion_ops.py:131-147, dual_quaternion_ops.py:122-153 differentiated), dbias += (nullable); workspace: Cout * Cin *
+ * kh * kw floats.  Needs SELD_DETERMINISTIC set (SELD_EUNSUPPORTED otherwise). */
+size_t seld_hc_conv_bwd_weight_det_workspace(const seld_conv_desc* desc);
+int seld_hc_conv_bwd_weight_det(const seld_conv_desc* desc, const float* x, const float* dy, float* const dw[8], float* dbias,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradients of a LIST of dual-quaternion convolutions in one grouped, persistent launch per shape family
  * (csrc/hcq_wgrad_grp.hip): dw[c] += d loss / d W_c for every job, i.e. dual_quaternion_conv
  * (dual_quaternion/dual_quaternion_ops.py:111-153) differentiated w.r.t. its eight component weights, which the reference

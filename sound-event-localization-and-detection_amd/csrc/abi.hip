@@ -37,6 +37,7 @@ static void load_env_locked() {
     e.hcq_no_first = flag("SELD_HCQ_NO_FIRST");
     e.hcq_no_pool = flag("SELD_HCQ_NO_POOL");
     e.hcq_wgrad_row = flag("SELD_HCQ_WGRAD_ROW");
+    e.deterministic = flag("SELD_DETERMINISTIC");
     e.wgrad_norow = flag("SELD_WGRAD_NOROW");
     e.wgrad_slow = flag("SELD_WGRAD_SLOW");
     e.mha_no_mfma = flag("SELD_MHA_NO_MFMA");

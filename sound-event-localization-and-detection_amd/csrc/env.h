@@ -7,6 +7,9 @@
 //   SELD_CONV_NOVEC / SELD_CONV_NOFAST / SELD_CONV_NO_SMALLK / SELD_NO_FWD_PAIR / SELD_CONV_PAIR / SELD_CONV_NO_HCQ / SELD_HCQ_NO_FIRST / SELD_HCQ_NO_POOL / SELD_HCQ_WGRAD_DQ / SELD_HCQ_WGRAD_ROW
 //   SELD_WGRAD_NOROW / SELD_WGRAD_SLOW / SELD_WGRAD_CFG=0..5 / SELD_WGRAD_WGS=n / SELD_SMALLK_WGS=n
 //   SELD_MHA_NO_MFMA
+//   SELD_DETERMINISTIC    run-to-run reproducible results: reductions that are normally split over workgroups and folded
+//                         with float atomics (BatchNorm statistics, weight-gradient splits, bias / loss sums) run as ONE
+//                         ordered chain per output element -- same values up to summation order, slower
 // Timing-experiment switches that switch parts of a kernel OFF and therefore give WRONG results exist only in
 // builds compiled with -DSELD_TUNING (never the shipped library):
 //   SELD_VEC_DBG, SELD_WGRAD_DBG, SELD_SMALLK_DBG, SELD_SMALLK_NW
@@ -22,6 +25,7 @@ struct SeldEnv {
     bool hcq_wgrad_row = false;                     // SELD_HCQ_WGRAD_ROW: dual-quaternion weight gradients on the 24-product row kernel
     bool hcq_no_pool = false;                       // SELD_HCQ_NO_POOL: first stage without the pooling convolution kernel
     bool hcq_no_first = false;                      // SELD_HCQ_NO_FIRST: first layers without the row-walking kernel
+    bool deterministic = false;                     // SELD_DETERMINISTIC: every reduction in a fixed order (no multi-contributor float atomics)
     bool wgrad_norow = false, wgrad_slow = false, mha_no_mfma = false;
     int wgrad_cfg = -1;                             // -1 = not forced, else 0..5
     long long wgrad_wgs = 0, smallk_wgs = 0;        // 0 = default

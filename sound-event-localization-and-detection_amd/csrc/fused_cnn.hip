@@ -10,6 +10,7 @@
 //             gradient w.r.t. the conv output.
 // The BatchNorm batch statistics themselves come from the convolution's epilogue (SELD_EPI_STATS).
 #include "common.h"
+#include "env.h"
 
 namespace seld {
 
@@ -107,8 +108,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const floa
     const float inv_g = degenerate ? 0.f : 1.0f / gamma[c];
     const float be = beta[c];
     const long long M = (long long)N * S;
-    const long long beg = (long long)blockIdx.x * 8192;
-    long long end = beg + 8192;
+    const long long chunk = gridDim.x == 1 ? M : 8192;          // SELD_DETERMINISTIC: one workgroup per channel
+    const long long beg = (long long)blockIdx.x * chunk;
+    long long end = beg + chunk;
     if (end > M) end = M;
     float v0 = 0.f, v1 = 0.f;
     // One 64-bit division per workgroup, 32-bit arithmetic per element; a thread owns 4 consecutive elements (S % 4 == 0:
@@ -330,7 +332,7 @@ extern "C" int seld_bn_relu_pool_bwd_coef_drop(const float* dpooled, const float
     hipStream_t st = (hipStream_t)stream;
     const int S = g.OH * g.OW;
     const long long M = (long long)N * S;
-    hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel, dim3((unsigned)((M + 8191) / 8192), C), dim3(256), 0, st, dpooled, pooled,
+    hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel, dim3(env().deterministic ? 1u : (unsigned)((M + 8191) / 8192), C), dim3(256), 0, st, dpooled, pooled,
                        N, C, S, gamma, beta, y, idx, g, mean, invstd, red, dr);
     rc = check_launch();
     if (rc) return rc;
@@ -358,7 +360,7 @@ extern "C" int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, 
     hipStream_t st = (hipStream_t)stream;
     const int S = g.OH * g.OW;
     const long long M = (long long)N * S;
-    hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel, dim3((unsigned)((M + 8191) / 8192), C), dim3(256), 0, st, dpooled, pooled,
+    hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel, dim3(env().deterministic ? 1u : (unsigned)((M + 8191) / 8192), C), dim3(256), 0, st, dpooled, pooled,
                        N, C, S, gamma, beta, y, idx, g, mean, invstd, red, DropP{0.f, 1.f, 0, 0, nullptr});
     rc = check_launch();
     if (rc) return rc;

@@ -453,6 +453,7 @@ static int wgrad_splits(const seld_conv_desc* d, int o[2], int bm, int bn, Wgrad
     if (env().wgrad_wgs) slots = env().wgrad_wgs;
     tiles *= (p->nslots > 1 ? 2 : 1);                     // a pair launch carries two gradients
     long long want = slots / tiles;                       // floor: stay within one generation
+    if (env().deterministic) want = 1;                    // one position range per tile: a single contribution per element
     const long long maxs = (Ptot + 511) / 512;            // at least 512 positions per split
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
@@ -680,6 +681,74 @@ extern "C" int seld_hc_conv_bwd_weight(const seld_conv_desc* d, const float* x, 
                                        size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     return wgrad_run(d, x, dy, dw, dbias, 0, (hipStream_t)stream);
+}
+
+// Hamilton fold of a real (Cout, Cin, K) gradient into the component gradients: element (comp, o, i, k) += the signed sum of
+// the blocks (po, qi) of the real matrix that hold it, in a fixed order
+struct DetFoldP {
+    const float* full;
+    float* dw[8];
+    int A, OA, IA, K;
+};
+__global__ __launch_bounds__(256) void hc_wgrad_det_fold_kernel(const DetFoldP p) {
+    const int per = p.OA * p.IA * p.K;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.A * per) return;
+    const int comp = e / per;
+    int rem = e - comp * per;
+    const int o = rem / (p.IA * p.K);
+    rem -= o * p.IA * p.K;
+    const int i = rem / p.K, k = rem - i * p.K;
+    float a = 0.f;
+    for (int po = 0; po < p.A; ++po)
+        for (int qi = 0; qi < p.A; ++qi) {
+            float sign;
+            if (block_comp(p.A, po, qi, &sign) != comp) continue;
+            a += sign * p.full[((size_t)(po * p.OA + o) * (p.A * p.IA) + (qi * p.IA + i)) * p.K + k];
+        }
+    p.dw[comp][((size_t)o * p.IA + i) * p.K + k] += a;
+}
+
+/* Reproducible weight gradient of any convolution this library takes (SELD_DETERMINISTIC mode of the host mirror):
+ * the layer is differentiated as the REAL convolution the reference assembles (quaternion_ops.py:131-147,
+ * dual_quaternion_ops.py:122-153) with ONE position range per output tile -- every element of the (Cout, Cin, K) gradient
+ * has a single contributor -- into `workspace` (Cout * Cin * K floats), and a fold adds the signed blocks to dw[c] in a fixed
+ * order.  Slow (no split over positions); same values as seld_hc_conv_bwd_weight_acc up to summation order. */
+extern "C" size_t seld_hc_conv_bwd_weight_det_workspace(const seld_conv_desc* d) {
+    if (hc_validate(d) != SELD_OK) return 0;
+    return (size_t)d->Cout * d->Cin * d->k[0] * d->k[1] * sizeof(float);
+}
+extern "C" int seld_hc_conv_bwd_weight_det(const seld_conv_desc* d, const float* x, const float* dy, float* const dw[8],
+                                           float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = hc_validate(d);
+    if (rc) return rc;
+    if (!x || !dy || !dw || !workspace) return SELD_EINVAL;
+    if (workspace_bytes < seld_hc_conv_bwd_weight_det_workspace(d)) return SELD_EWORKSPACE;
+    if (!env().deterministic) return SELD_EUNSUPPORTED;           // the single-range launch plan is tied to the switch
+    hipStream_t st = (hipStream_t)stream;
+    seld_conv_desc real = *d;
+    real.algebra = 1;
+    float* full[8] = {(float*)workspace, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    rc = wgrad_run(&real, x, dy, full, nullptr, 0, st);           // zero-fills `full`, then one contribution per element
+    if (rc) return rc;
+    DetFoldP f{};
+    f.full = (const float*)workspace; f.A = d->algebra; f.OA = d->Cout / d->algebra; f.IA = d->Cin / d->algebra;
+    f.K = d->k[0] * d->k[1];
+    for (int i = 0; i < d->algebra; ++i) {
+        if (!dw[i]) return SELD_EINVAL;
+        f.dw[i] = dw[i];
+    }
+    const int total = d->algebra * f.OA * f.IA * f.K;
+    hipLaunchKernelGGL(hc_wgrad_det_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, f);
+    rc = check_launch();
+    if (rc) return rc;
+    if (dbias) {
+        int o[2];
+        hc_out_shape(d, o);
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(d->Cout), dim3(256), 0, st, dy, d->N, d->Cout, o[0] * o[1], dbias);
+        rc = check_launch();
+    }
+    return rc;
 }
 
 // dw[c] += ..., dbias += ...  (gradient accumulation straight into the optimiser's flat gradient buffer)

@@ -8,6 +8,7 @@
 // These layers are the two classifier heads (rows = B*T/8, <= 0.2 % of the model's flops), so a
 // plain LDS-tiled fp32 VALU GEMM is used (64 x 64 tile, 4 x 4 per thread).
 #include "common.h"
+#include "env.h"
 
 namespace seld {
 
@@ -361,7 +362,7 @@ extern "C" int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_feature
     if (dw) {
         if (!x) return SELD_EINVAL;
         if (!workspace || workspace_bytes < seld_hc_linear_bwd_workspace(kind, in_features, out_features)) return SELD_EWORKSPACE;
-        const int rps = 128;
+        const int rps = env().deterministic ? rows : 128;       // one row range: a single contribution per element
         dim3 grid((out_features + 63) / 64, (in_features + 63) / 64, (rows + rps - 1) / rps);
         if (hipMemsetAsync(workspace, 0, (size_t)in_features * out_features * sizeof(float), st) != hipSuccess) return SELD_ELAUNCH;
         hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, st, rows, rps, in_features, out_features, x, dy, (float*)workspace);
@@ -375,7 +376,7 @@ extern "C" int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_feature
         if (rc) return rc;
     }
     if (dbias) {
-        const int rpb = 64;
+        const int rpb = env().deterministic ? rows : 64;
         if (hipMemsetAsync(dbias, 0, (size_t)out_features * sizeof(float), st) != hipSuccess) return SELD_ELAUNCH;
         hipLaunchKernelGGL(column_sum_kernel, dim3((out_features + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, st, dy, rows,
                            out_features, rpb, dbias);

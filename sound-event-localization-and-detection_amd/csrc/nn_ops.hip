@@ -2,6 +2,7 @@
 // for gfx950.  All HBM-bound: 16-byte loads/stores along the contiguous S axis, per-channel
 // reductions by wave shuffles + one atomic per wave (guide: Appendix B "Reduction").
 #include "common.h"
+#include "env.h"
 
 namespace seld {
 
@@ -33,8 +34,9 @@ template <typename F>
 __device__ __forceinline__ void channel_walk(int N, int C, int S, int c, F&& f) {
     // calls f(offset_of_4_or_1_elements, count) for this block's slice of channel c
     const long long M = (long long)N * S;
-    const long long beg = (long long)blockIdx.x * RED_CHUNK;
-    long long end = beg + RED_CHUNK;
+    const long long chunk = gridDim.x == 1 ? M : RED_CHUNK;      // one workgroup per channel (SELD_DETERMINISTIC): the whole range
+    const long long beg = (long long)blockIdx.x * chunk;
+    long long end = beg + chunk;
     if (end > M) end = M;
     if ((S & 3) == 0) {
         for (long long i = beg + (long long)threadIdx.x * 4; i < end; i += (long long)blockDim.x * 4) {
@@ -858,11 +860,14 @@ static inline unsigned grid_for(long long work_items, int per_block = 256, int c
 
 using namespace seld;
 #define ST(s) ((hipStream_t)(s))
+// chunks of a per-channel reduction: one (the block's single atomic add per output is then the only contribution) when
+// SELD_DETERMINISTIC is set
+static inline unsigned red_chunks(long long M) { return env().deterministic ? 1u : (unsigned)((M + RED_CHUNK - 1) / RED_CHUNK); }
 
 extern "C" int seld_channel_stats(const float* x, int32_t N, int32_t C, int32_t S, float* stats, void* stream) {
     if (!x || !stats || N <= 0 || C <= 0 || S <= 0) return SELD_EINVAL;
     const long long M = (long long)N * S;
-    dim3 grid((unsigned)((M + RED_CHUNK - 1) / RED_CHUNK), C);
+    dim3 grid(red_chunks(M), C);
     hipLaunchKernelGGL(channel_stats_kernel, grid, dim3(256), 0, ST(stream), x, N, C, S, stats);
     return check_launch();
 }
@@ -917,7 +922,7 @@ extern "C" int seld_bn_act_bwd_reduce(const float* dy, const float* x, const flo
     (void)gamma; (void)beta;
     if (!dy || !x || !y || !red) return SELD_EINVAL;
     const long long M = (long long)N * S;
-    dim3 grid((unsigned)((M + RED_CHUNK - 1) / RED_CHUNK), C);
+    dim3 grid(red_chunks(M), C);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, ST(stream), dy, x, y, N, C, S, mean, invstd, act, red);
     return check_launch();
 }
@@ -983,8 +988,8 @@ extern "C" int seld_gate_bwd_reduce(const float* dy, const float* yf, const floa
                                     const float* mask, float* red, void* stream) {
     if (!dy || !yf || !yg || !red) return SELD_EINVAL;
     const long long M = (long long)N * S;
-    dim3 grid((unsigned)((M + RED_CHUNK - 1) / RED_CHUNK), C);
-    if (S % 4 == 0 && (long long)N * C < (1LL << 31))
+    dim3 grid(red_chunks(M), C);
+    if (S % 4 == 0 && (long long)N * C < (1LL << 31) && !env().deterministic)
         hipLaunchKernelGGL(gate_bwd_reduce_row_kernel, dim3(row_grid((long long)N * C)), dim3(256), 0, ST(stream), dy, yf, yg,
                            N * C, C, S, mk_gate(mean_f, invstd_f, gamma_f, beta_f, mean_g, invstd_g, gamma_g, beta_g), mask, red);
     else
@@ -1119,7 +1124,7 @@ extern "C" int seld_loss_fwd_bwd(const float* sed, const float* doa, const float
                                  int32_t n_doa, float w_sed, float w_doa, float* loss, float* dsed, float* ddoa,
                                  void* stream) {
     if (!sed || !doa || !target || !loss || rows <= 0 || n_sed <= 0 || n_doa <= 0) return SELD_EINVAL;
-    hipLaunchKernelGGL(loss_kernel, dim3(grid_for(rows * (n_sed + n_doa), 256, 1024)), dim3(256), 0, ST(stream), sed, doa,
+    hipLaunchKernelGGL(loss_kernel, dim3(env().deterministic ? 1u : grid_for(rows * (n_sed + n_doa), 256, 1024)), dim3(256), 0, ST(stream), sed, doa,
                        target, (long long)rows, n_sed, n_doa, w_sed, w_doa, loss, dsed, ddoa);
     return check_launch();
 }

@@ -103,6 +103,14 @@ class _Timed:
         return False
 
 
+def deterministic():
+    """SELD_DETERMINISTIC=1: run-to-run reproducible training (include/seld_hip.h).  The library reads the switch itself
+    (reductions in one ordered chain); here: BatchNorm statistics by seld_channel_stats instead of the convolution
+    epilogues' atomics, weight gradients by the grouped kernels (no atomics) or seld_hc_conv_bwd_weight_det, no side
+    stream.  Set it before the first library call (or call _lib.reload_env())."""
+    return os.environ.get("SELD_DETERMINISTIC", "0") not in ("", "0")
+
+
 def _req(t, name):
     if t is None:
         return None
@@ -159,6 +167,11 @@ def conv_fwd(desc, x, ws, bias=None, out=None, epilogue=0, addend=None, stats=No
     bias = _req(bias, "bias")
     o = conv_out_shape(desc)
     y = out if out is not None else torch.empty(_y_shape(desc, o), device=x.device, dtype=torch.float32)
+    if stats is not None and deterministic():
+        # statistics by one ordered reduction per channel instead of the epilogue's float atomics
+        y = conv_fwd(desc, x, ws, bias, out=y, epilogue=epilogue & ~L.SELD_EPI_STATS, addend=addend, stats=None)
+        channel_stats(y, out=stats)
+        return y
     wp = hcq_weights.get(desc, 0, ws) if desc.algebra > 1 else None
     if wp is not None:                      # 8-multiplication Hamilton product (csrc/hcq_conv.hip)
         with _Timed(desc, 0, label=_hcq_label_cached(desc, 0, 1) if kernel_timer.active else None):
@@ -199,6 +212,8 @@ def conv_bwd_data(desc, dy, ws, x_shape, ahead=None):
 
 
 def _hcq_wgrad_ok(desc, npair=1):
+    if deterministic():
+        return False
     key = (bytes(desc), npair, "wgrad")
     v = _hcq_labels.get(key)
     if v is None:
@@ -340,7 +355,10 @@ class _DeferredWgrads:
         return os.environ.get("SELD_WGRAD_GROUP", "1") != "0"
 
     def takes(self, desc):
-        return desc.algebra == 8 and self.enabled() and wgrad_group_family(desc) in self.FAMILIES
+        if desc.algebra != 8 or not self.enabled():
+            return False
+        fam = wgrad_group_family(desc)
+        return fam in self.FAMILIES or (fam == 3 and deterministic())        # the grouped kernels have no atomics
 
     def add(self, desc, x, dy, dws):
         # the stream this backward node runs on produced dy (branch B of the two-stream model runs on its own queue)
@@ -393,6 +411,18 @@ def conv_bwd_weight(desc, x, dy, w_shape, want_bias, into=None, bias_into=None):
     accumulating entry point: the kernel adds straight into them and nothing is returned for autograd."""
     x = _req(x, "x")
     dy = _req(dy, "dy")
+    if deterministic():
+        lib = L.lib()
+        lib.seld_hc_conv_bwd_weight_det_workspace.restype = ctypes.c_size_t
+        nbytes = int(lib.seld_hc_conv_bwd_weight_det_workspace(ctypes.byref(desc)))
+        wsb = torch.empty(max(nbytes, 16), device=x.device, dtype=torch.uint8)
+        dws = into if into is not None else [torch.zeros(w_shape, device=x.device, dtype=torch.float32) for _ in range(desc.algebra)]
+        dbias = bias_into if bias_into is not None else (torch.zeros(desc.Cout, device=x.device, dtype=torch.float32) if want_bias else None)
+        with _Timed(desc, 2):
+            L.check(lib.seld_hc_conv_bwd_weight_det(ctypes.byref(desc), L.ptr(x), L.ptr(dy), L.ptr_array8(dws), L.ptr(dbias),
+                                                    L.ptr(wsb), ctypes.c_size_t(wsb.numel()), L.current_stream()),
+                    "seld_hc_conv_bwd_weight_det")
+        return (None, None) if into is not None else (dws, dbias)
     if not want_bias and bias_into is None and _hcq_wgrad_ok(desc):
         if into is not None:
             hcq_wgrad_acc(desc, x, dy, into)
@@ -454,7 +484,7 @@ _side = {"stream": None, "dirty": False, "keep": []}
 
 
 def _side_enabled():
-    return os.environ.get("SELD_WGRAD_SIDE_STREAM", "1") != "0"
+    return os.environ.get("SELD_WGRAD_SIDE_STREAM", "1") != "0" and not deterministic()
 
 
 def join_side_stream():
@@ -871,27 +901,34 @@ class HyperConvPairFn(torch.autograd.Function):
         o = conv_out_shape(desc)
         yA = torch.empty(_y_shape(desc, o), device=x.device, dtype=torch.float32)
         yB = torch.empty_like(yA)
-        epiA = (L.SELD_EPI_ADD if addA is not None else 0) | (L.SELD_EPI_STATS if statsA is not None else 0)
-        epiB = (L.SELD_EPI_ADD if addB is not None else 0) | (L.SELD_EPI_STATS if statsB is not None else 0)
+        det_stats = deterministic() and (statsA is not None or statsB is not None)
+        kstA, kstB = (None, None) if det_stats else (statsA, statsB)         # statistics the kernels gather themselves
+        epiA = (L.SELD_EPI_ADD if addA is not None else 0) | (L.SELD_EPI_STATS if kstA is not None else 0)
+        epiB = (L.SELD_EPI_ADD if addB is not None else 0) | (L.SELD_EPI_STATS if kstB is not None else 0)
         one_launch = all(v == 1 for v in k)          # 1x1 pairs run the pair instantiation of the kernel
         # (issuing the second of two launches on the side stream was measured: 14.69 vs 14.58 ms per step, not kept)
         wp = hcq_weights.get(desc, 0, wsA, wsB) if algebra > 1 else None
         if wp is not None:                           # both convolutions in one launch of the fast-product kernel
             with _Timed(desc, 0, 2, label=_hcq_label_cached(desc, 0, 2) if kernel_timer.active else None):
                 hcq_conv(desc, 0, x, wp, (yA, yB), (_req(biasA, "bias"), _req(biasB, "bias")), (epiA, epiB),
-                         (_req(addA, "addend"), _req(addB, "addend")), (statsA, statsB))
+                         (_req(addA, "addend"), _req(addB, "addend")), (kstA, kstB))
         else:
             with _Timed(desc, 0, 2, one_launch):
                 rc = L.lib().seld_hc_conv_pair_fwd(
                     ctypes.byref(desc), L.ptr(x), L.ptr_array8([_req(w, "w") for w in wsA]),
                     L.ptr_array8([_req(w, "w") for w in wsB]), L.ptr(_req(biasA, "bias")), L.ptr(_req(biasB, "bias")),
                     L.ptr(yA), L.ptr(yB), ctypes.c_int32(epiA), ctypes.c_int32(epiB), L.ptr(_req(addA, "addend")),
-                    L.ptr(_req(addB, "addend")), L.ptr(statsA), L.ptr(statsB), L.current_stream())
+                    L.ptr(_req(addB, "addend")), L.ptr(kstA), L.ptr(kstB), L.current_stream())
             if rc == -4:       # SELD_EUNSUPPORTED: e.g. the two weight sets lie more than 4 GB apart
-                conv_fwd(desc, x, wsA, biasA, out=yA, epilogue=epiA, addend=addA, stats=statsA)
-                conv_fwd(desc, x, wsB, biasB, out=yB, epilogue=epiB, addend=addB, stats=statsB)
+                conv_fwd(desc, x, wsA, biasA, out=yA, epilogue=epiA, addend=addA, stats=kstA)
+                conv_fwd(desc, x, wsB, biasB, out=yB, epilogue=epiB, addend=addB, stats=kstB)
             else:
                 L.check(rc, "seld_hc_conv_pair_fwd")
+        if det_stats:
+            if statsA is not None:
+                channel_stats(yA, out=statsA)
+            if statsB is not None:
+                channel_stats(yB, out=statsB)
         ctx.desc, ctx.algebra = desc, algebra
         ctx.params = (wsA, wsB, biasA, biasB)
         ctx.wt_ahead = None
@@ -951,7 +988,7 @@ class HyperConvPairFn(torch.autograd.Function):
                     _on_side_stream(pair_wgrad_fast, x, dyA, dyB)
                 else:
                     pair_wgrad_fast()
-            elif dirA is not None and dirB is not None and _pair_ok(desc, 2):
+            elif dirA is not None and dirB is not None and _pair_ok(desc, 2) and not deterministic():
                 def pair_wgrad():
                     with _Timed(desc, 2, 2):
                         L.check(lib.seld_hc_conv_pair_bwd_weight_acc(ctypes.byref(desc), L.ptr(x), L.ptr(dyA), L.ptr(dyB),
@@ -1991,6 +2028,11 @@ def conv_bn_relu_pool(x, ws, bias, bn, ph, pw, stride, padding, dilation, drop_p
     if fused:
         pad = padding if isinstance(padding, (tuple, list)) else (padding, padding)
         fused = tuple(pad) == (1, 1)          # 'same' 3x3: the output has the input's height and width
+    if fused and deterministic():
+        # only the path without the convolution output is free of atomics (Gram statistics, partials + ordered folds)
+        desc_ = make_conv_desc(tuple(x.shape), ws[0].shape[0] * len(ws), len(ws), k, stride, padding, dilation)
+        fused = (len(ws) > 1 and int(ph) == 8 and bn.training and _first_stage_nostore(desc_) and
+                 hcq_weights.get(desc_, 2, ws) is not None)
     if fused:
         return ConvBnReluPoolFn.apply(x, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
                                       bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(ph), _nbt(bn),
