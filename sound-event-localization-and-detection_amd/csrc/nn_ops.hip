@@ -789,8 +789,12 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sed
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n, float lr,
-                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                   float b1, float b2, float eps, float wd, float step,
                                                    float gscale) {
+    // bias corrections ON THE DEVICE, with the expressions of adam_state_kernel: an eager step and a replayed one then
+    // produce the same bits (the host's powf rounds differently now and then)
+    const float bc1 = 1.0f - powf(b1, step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(b2, step));
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float grad = g[i] * gscale;
         const float pv = p[i];
@@ -1134,10 +1138,8 @@ extern "C" int seld_adam_flat(float* param, const float* grad, float* exp_avg, f
                               void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return SELD_EINVAL;
     if (n == 0) return SELD_OK;
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq,
-                       (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+                       (long long)n, lr, beta1, beta2, eps, weight_decay, (float)step, grad_scale);
     return check_launch();
 }
 extern "C" int seld_adam_flat_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
