@@ -342,7 +342,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['name']} train step, F={args.freq} T=512 (U=L={w['U'] * (args.freq // 128)}, SURVEY F3), "
                                    f"batch {batch}/GPU, random-init weights", "global_batch": batch * world,
-                       "parallelism": f"dp{world}", "step_mode": step_mode},
+                       "parallelism": f"dp{world}", "step_mode": step_mode,
+                       "deterministic": bool(H.deterministic())},
             "loss": round(final_loss, 6),
             # world size as torch.distributed sees it after init (1 = no process group) and the backend that carried it
             "rccl_ranks": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
