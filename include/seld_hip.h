@@ -161,8 +161,9 @@ int seld_hc_conv_kernel_label(const seld_conv_desc* d, int32_t which, char* buf,
 
 int seld_hc_linear_fwd(int32_t kind, int32_t rows, int32_t in_features, int32_t out_features,
                        const float* x, const float* const w[8], const float* bias, float* y, void* stream);
-/* dx = dy @ M^T (nullable), dw[c] = folded x^T @ dy, dbias = column sums of dy (nullable).
- * workspace: in_features * out_features floats. */
+/* dx = dy @ M^T (nullable), dw[c] = folded x^T @ dy (nullable), dbias = column sums of dy (nullable).
+ * workspace: seld_hc_linear_bwd_workspace bytes (up to 8 row splits of x^T @ dy and of the column sums, written with
+ * plain stores and added in a fixed order by the fold: nothing is zeroed, no atomics, run-to-run identical). */
 size_t seld_hc_linear_bwd_workspace(int32_t kind, int32_t in_features, int32_t out_features);
 int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_features, int32_t out_features,
                        const float* x, const float* dy, const float* const w[8],
@@ -217,6 +218,20 @@ int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, const uint8
                           int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
                           const float* invstd, const float* gamma, const float* beta, int32_t train,
                           float* red, float* dy, void* stream);
+/* The stage's Dropout (model.py:282) in the same passes, for the shapes seld_bn_relu_pool_drop_ok accepts (pw == 1,
+ * W % 4 == 0, H % ph == 0): forward also writes dropped = pooled * mask (the mask seld_dropout_fwd draws for the same
+ * seed / offset / state on the pooled tensor); backward takes dpooled = the gradient BEHIND the Dropout and replays the
+ * mask while it loads it.  drop_p == 0: identical to the two entries above (dropped is not written). */
+int seld_bn_relu_pool_drop_ok(int32_t H, int32_t W, int32_t ph, int32_t pw);
+int seld_bn_relu_pool_fwd_drop(const float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                               const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               float* pooled, uint8_t* idx, float drop_p, uint64_t seed, uint64_t offset,
+                               const uint64_t* state, float* dropped, void* stream);
+int seld_bn_relu_pool_bwd_drop(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                               int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, int32_t train,
+                               float* red, float* dy, float drop_p, uint64_t seed, uint64_t offset,
+                               const uint64_t* state, void* stream);
 
 /* The same backward for a convolution whose INPUT needs no gradient (the first layer), without ever writing the
  * gradient w.r.t. the conv output (1.6 GB at batch 32):
@@ -462,8 +477,10 @@ int seld_transpose_ntc_nct(const float* x, int32_t N, int32_t T, int32_t C, floa
  * Loss (train.py:186-204): loss = w_sed * BCELoss(sed, t_sed) + w_doa * MSELoss(doa, t_doa), mean
  * reductions (train.py:498-499); sed/doa are the model OUTPUTS (after Sigmoid / Tanh).
  * target is (rows, n_sed + n_doa) row-major as produced by the preprocessing (train.py:191-192).
- * Accumulates the scalar into loss[0] (caller pre-zeroes) and, if non-null, writes dloss/dsed and
- * dloss/ddoa (torch.nn.BCELoss semantics: logs clamped at -100, backward denominator >= 1e-12).
+ * WRITES the scalar to loss[0] (workgroup sums added in a fixed order by the last workgroup to finish: no pre-zeroing,
+ * run-to-run identical; the scratch is a per-device static of the library, so evaluations on ONE device must not overlap
+ * on different streams) and, if non-null, writes dloss/dsed and dloss/ddoa (torch.nn.BCELoss semantics: logs clamped at
+ * -100, backward denominator >= 1e-12).
  * ------------------------------------------------------------------------------------------ */
 int seld_loss_fwd_bwd(const float* sed, const float* doa, const float* target,
                       int64_t rows, int32_t n_sed, int32_t n_doa, float w_sed, float w_doa,

@@ -58,13 +58,15 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_v4_kernel(const float* _
                                                                   const float* __restrict__ invstd,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta,
-                                                                  float* __restrict__ pooled, uint8_t* __restrict__ idx) {
+                                                                  float* __restrict__ pooled, uint8_t* __restrict__ idx,
+                                                                  DropP dr, float* __restrict__ dropped) {
     const int ow = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (ow >= g.OW) return;
     const int oh = blockIdx.y;
     const long long nc = blockIdx.z;
     const int c = (int)(nc % g.C);
     const long long i = (nc * g.OH + oh) * g.OW + ow;
+    if (dr.p > 0.f && dr.state) dr.offset += dr.state[0];
     const float a = gamma[c] * invstd[c];
     const float b = beta[c] - mean[c] * a;
     const float* base = y + ((size_t)nc * g.H + (size_t)oh * g.ph) * g.W + ow;
@@ -90,6 +92,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_v4_kernel(const float* _
     }
     *reinterpret_cast<float4*>(pooled + i) = make_float4(best[0], best[1], best[2], best[3]);
     *reinterpret_cast<uchar4*>(idx + i) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+    if (dr.p > 0.f) {            // the stage's Dropout in the same pass: the mask seld_dropout_fwd draws for element group i / 4
+        const float4 mk = dropout_mask4(dr.offset + (uint64_t)(i >> 2), dr.seed, dr.p, dr.scale);
+        *reinterpret_cast<float4*>(dropped + i) = make_float4(best[0] * mk.x, best[1] * mk.y, best[2] * mk.z, best[3] * mk.w);
+    }
 }
 
 // red[c] += sum dz * xhat, red[C + c] += sum dz   over the pooled elements of channel c
@@ -228,9 +234,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_v4_kernel(const fl
                                                                         const float* __restrict__ invstd,
                                                                         const float* __restrict__ gamma,
                                                                         const float* __restrict__ red, float inv_count,
-                                                                        int train, float* __restrict__ dy) {
+                                                                        int train, float* __restrict__ dy, DropP dr) {
     const int ow = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (ow >= g.OW) return;
+    if (dr.p > 0.f && dr.state) dr.offset += dr.state[0];
     const int oh = blockIdx.y;
     const long long nc = blockIdx.z;
     const int c = (int)(nc % g.C);
@@ -242,7 +249,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_v4_kernel(const fl
     const float c1 = -a * is * k2, c0 = a * (mu * is * k2 - k1);
     const size_t o = ((size_t)nc * g.OH + oh) * g.OW + ow;
     const float4 pz = *reinterpret_cast<const float4*>(pooled + o);
-    const float4 dp = *reinterpret_cast<const float4*>(dpooled + o);
+    float4 dp = *reinterpret_cast<const float4*>(dpooled + o);
+    if (dr.p > 0.f) {                     // dpooled is the gradient behind the stage's Dropout: the same mask
+        const float4 mk = dropout_mask4(dr.offset + (uint64_t)(o >> 2), dr.seed, dr.p, dr.scale);
+        dp.x *= mk.x; dp.y *= mk.y; dp.z *= mk.z; dp.w *= mk.w;
+    }
     const uchar4 am = *reinterpret_cast<const uchar4*>(idx + o);
     const float dz[4] = {pz.x > 0.f ? dp.x : 0.f, pz.y > 0.f ? dp.y : 0.f, pz.z > 0.f ? dp.z : 0.f, pz.w > 0.f ? dp.w : 0.f};
     const int ai[4] = {am.x, am.y, am.z, am.w};
@@ -291,9 +302,9 @@ static int mk_geom(PoolGeom& g, int N, int C, int H, int W, int ph, int pw) {
     return SELD_OK;
 }
 
-extern "C" int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
-                                     const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                     float* pooled, uint8_t* idx, void* stream) {
+static int bn_relu_pool_fwd_impl(const float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                float* pooled, uint8_t* idx, const DropP& dr, float* dropped, void* stream) {
     PoolGeom g;
     int rc = mk_geom(g, N, C, H, W, ph, pw);
     if (rc) return rc;
@@ -302,17 +313,40 @@ extern "C" int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32
         const dim3 grid((g.OW / 4 + 127) / 128, g.OH, (unsigned)g.NC);
         if (ph == 8)
             hipLaunchKernelGGL(bn_relu_pool_fwd_v4_kernel<8>, grid, dim3(128), 0, (hipStream_t)stream, y, g, mean, invstd, gamma,
-                               beta, pooled, idx);
+                               beta, pooled, idx, dr, dropped);
         else if (ph == 2)
             hipLaunchKernelGGL(bn_relu_pool_fwd_v4_kernel<2>, grid, dim3(128), 0, (hipStream_t)stream, y, g, mean, invstd, gamma,
-                               beta, pooled, idx);
+                               beta, pooled, idx, dr, dropped);
         else
             hipLaunchKernelGGL(bn_relu_pool_fwd_v4_kernel<0>, grid, dim3(128), 0, (hipStream_t)stream, y, g, mean, invstd, gamma,
-                               beta, pooled, idx);
-    } else
+                               beta, pooled, idx, dr, dropped);
+    } else {
+        if (dr.p > 0.f) return SELD_EUNSUPPORTED;
         hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((g.OW + 255) / 256, g.OH, (unsigned)g.NC), dim3(256), 0, (hipStream_t)stream, y, g,
                            mean, invstd, gamma, beta, pooled, idx);
+    }
     return check_launch();
+}
+
+extern "C" int seld_bn_relu_pool_fwd(const float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                                     const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     float* pooled, uint8_t* idx, void* stream) {
+    return bn_relu_pool_fwd_impl(y, N, C, H, W, ph, pw, mean, invstd, gamma, beta, pooled, idx, DropP{0.f, 1.f, 0, 0, nullptr},
+                                 nullptr, stream);
+}
+
+extern "C" int seld_bn_relu_pool_drop_ok(int32_t H, int32_t W, int32_t ph, int32_t pw) {
+    return pw == 1 && W % 4 == 0 && ph > 0 && H % ph == 0;
+}
+
+extern "C" int seld_bn_relu_pool_fwd_drop(const float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw,
+                                          const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                          float* pooled, uint8_t* idx, float drop_p, uint64_t seed, uint64_t offset,
+                                          const uint64_t* state, float* dropped, void* stream) {
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !dropped)) return SELD_EINVAL;
+    if (drop_p > 0.f && !seld_bn_relu_pool_drop_ok(H, W, ph, pw)) return SELD_EUNSUPPORTED;
+    return bn_relu_pool_fwd_impl(y, N, C, H, W, ph, pw, mean, invstd, gamma, beta, pooled, idx,
+                                 DropP{drop_p, 1.0f / (1.0f - drop_p), seed, offset, state}, dropped, stream);
 }
 
 // First half of seld_bn_relu_pool_bwd for a convolution whose INPUT needs no gradient (the first layer): the
@@ -349,10 +383,10 @@ extern "C" int seld_bn_relu_pool_bwd_coef(const float* dpooled, const float* poo
                                            coef, conv_dbias, 0.f, 0, 0, nullptr, stream);
 }
 
-extern "C" int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
-                                     int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
-                                     const float* invstd, const float* gamma, const float* beta, int32_t train,
-                                     float* red /* (2C) pre-zeroed: dgamma | dbeta */, float* dy, void* stream) {
+static int bn_relu_pool_bwd_impl(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                                int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
+                                const float* invstd, const float* gamma, const float* beta, int32_t train, float* red, float* dy,
+                                const DropP& dr, void* stream) {
     PoolGeom g;
     int rc = mk_geom(g, N, C, H, W, ph, pw);
     if (rc) return rc;
@@ -360,16 +394,36 @@ extern "C" int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, 
     hipStream_t st = (hipStream_t)stream;
     const int S = g.OH * g.OW;
     const long long M = (long long)N * S;
+    const bool v4 = pw == 1 && W % 4 == 0 && H % ph == 0;
+    if (dr.p > 0.f && !v4) return SELD_EUNSUPPORTED;
     hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel, dim3(env().deterministic ? 1u : (unsigned)((M + 8191) / 8192), C), dim3(256), 0, st, dpooled, pooled,
-                       N, C, S, gamma, beta, y, idx, g, mean, invstd, red, DropP{0.f, 1.f, 0, 0, nullptr});
+                       N, C, S, gamma, beta, y, idx, g, mean, invstd, red, dr);
     rc = check_launch();
     if (rc) return rc;
     const int OHx = (H + ph - 1) / ph, OWx = (W + pw - 1) / pw;
-    if (pw == 1 && W % 4 == 0 && H % ph == 0)
+    if (v4)
         hipLaunchKernelGGL(bn_relu_pool_bwd_apply_v4_kernel, dim3((g.OW / 4 + 127) / 128, g.OH, (unsigned)g.NC), dim3(128), 0, st,
-                           dpooled, pooled, idx, y, g, mean, invstd, gamma, red, 1.0f / (float)((long long)N * H * W), train, dy);
+                           dpooled, pooled, idx, y, g, mean, invstd, gamma, red, 1.0f / (float)((long long)N * H * W), train, dy, dr);
     else
         hipLaunchKernelGGL(bn_relu_pool_bwd_apply_kernel, dim3((OWx + 255) / 256, OHx, (unsigned)g.NC), dim3(256), 0, st, dpooled, pooled, idx, y,
                            g, mean, invstd, gamma, red, 1.0f / (float)((long long)N * H * W), train, dy);
     return check_launch();
+}
+
+extern "C" int seld_bn_relu_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                                     int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, int32_t train,
+                                     float* red /* (2C) pre-zeroed: dgamma | dbeta */, float* dy, void* stream) {
+    return bn_relu_pool_bwd_impl(dpooled, pooled, idx, y, N, C, H, W, ph, pw, mean, invstd, gamma, beta, train, red, dy,
+                                 DropP{0.f, 1.f, 0, 0, nullptr}, stream);
+}
+
+extern "C" int seld_bn_relu_pool_bwd_drop(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y,
+                                          int32_t N, int32_t C, int32_t H, int32_t W, int32_t ph, int32_t pw, const float* mean,
+                                          const float* invstd, const float* gamma, const float* beta, int32_t train,
+                                          float* red, float* dy, float drop_p, uint64_t seed, uint64_t offset,
+                                          const uint64_t* state, void* stream) {
+    if (drop_p < 0.f || drop_p >= 1.f) return SELD_EINVAL;
+    return bn_relu_pool_bwd_impl(dpooled, pooled, idx, y, N, C, H, W, ph, pw, mean, invstd, gamma, beta, train, red, dy,
+                                 DropP{drop_p, 1.0f / (1.0f - drop_p), seed, offset, state}, stream);
 }

@@ -210,9 +210,11 @@ __global__ __launch_bounds__(256) void linear_gemm48_kernel(const LinP p, int ro
         }
 }
 
-// dM[i][o] = sum_r x[r][i] * dy[r][o]
+// dM[z][i][o] = sum over the rows of split z of x[r][i] * dy[r][o]; dB[z][o] = the column sums of dy over the same rows
+// (written by the workgroups of the first input tile).  Plain stores, one writer per element: linear_fold_kernel adds the
+// splits in a fixed order -- no zeroed buffer, no atomics, the same bits every run.
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int rows_per_split, int in_f, int out_f, const float* __restrict__ x,
-                                                           const float* __restrict__ dy, float* __restrict__ dM) {
+                                                           const float* __restrict__ dy, float* __restrict__ dM, float* __restrict__ dB) {
     __shared__ float Xs[16][64 + 4];
     __shared__ float Ds[16][64 + 4];
     const int tid = threadIdx.x;
@@ -233,12 +235,14 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int rows_pe
             rd[t] = (r0 + r < rend && o0 + cc < out_f) ? dy[(size_t)(r0 + r) * out_f + o0 + cc] : 0.f;
         }
     };
+    float bs = 0.f;
     if (rbeg < rend) fetch(rbeg);
     for (int r0 = rbeg; r0 < rend; r0 += 16) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             Xs[rq + 4 * t][cc] = rx[t];
             Ds[rq + 4 * t][cc] = rd[t];
+            bs += rd[t];
         }
         __syncthreads();
         if (r0 + 16 < rend) fetch(r0 + 16);
@@ -261,21 +265,43 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int rows_pe
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ii = i0 + ti + i, oo = o0 + to + j;
-            if (ii < in_f && oo < out_f) atomicAdd(dM + (size_t)ii * out_f + oo, acc[i][j]);
+            if (ii < in_f && oo < out_f) dM[((size_t)blockIdx.z * in_f + ii) * out_f + oo] = acc[i][j];
         }
+    if (dB && blockIdx.y == 0) {                 // the loop's last barrier has passed: Xs is free
+        Xs[rq][cc] = bs;
+        __syncthreads();
+        if (rq == 0 && o0 + cc < out_f) dB[(size_t)blockIdx.z * out_f + o0 + cc] = (Xs[0][cc] + Xs[1][cc]) + (Xs[2][cc] + Xs[3][cc]);
+    }
 }
 
-__global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, WPtrsMut dw) {
+// dw = the splits of dM added in order and folded onto the components; threads past the weights write dbias the same way
+__global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, const float* __restrict__ dB, int nz, WPtrsMut dw,
+                                   float* __restrict__ dbias) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t zs = (size_t)p.in_f * p.out_f;
+    auto at = [&](size_t e) {
+        float t = 0.f;
+        for (int z = 0; z < nz; ++z) t += dM[z * zs + e];
+        return t;
+    };
+    const int nw = p.kind == SELD_LIN_REAL ? p.in_f * p.out_f : p.IA * p.OA * p.kind;
+    if (idx >= nw) {
+        const int o = idx - nw;
+        if (dbias && o < p.out_f) {
+            float t = 0.f;
+            for (int z = 0; z < nz; ++z) t += dB[(size_t)z * p.out_f + o];
+            dbias[o] = t;
+        }
+        return;
+    }
+    if (!dw.p[0]) return;
     if (p.kind == SELD_LIN_REAL) {
-        if (idx >= p.in_f * p.out_f) return;
         const int o = idx / p.in_f, i = idx - o * p.in_f;
-        dw.p[0][idx] = dM[(size_t)i * p.out_f + o];
+        dw.p[0][idx] = at((size_t)i * p.out_f + o);
         return;
     }
     const int A = p.kind;
     const int per = p.IA * p.OA;
-    if (idx >= per * A) return;
     const int comp = idx / per;
     const int rem = idx - comp * per;
     const int c = rem / p.OA, oo = rem - c * p.OA;
@@ -285,25 +311,9 @@ __global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, W
             float sign;
             const int cc = (p.kind == SELD_LIN_QUAT) ? block_comp(4, b, a, &sign) : block_comp(8, a, b, &sign);
             if (cc != comp) continue;
-            total += sign * dM[(size_t)(a * p.IA + c) * p.out_f + (size_t)b * p.OA + oo];
+            total += sign * at((size_t)(a * p.IA + c) * p.out_f + (size_t)b * p.OA + oo);
         }
     dw.p[comp][rem] = total;
-}
-
-__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ x, int rows, int cols,
-                                                         int rows_per_block, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ty = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * rows_per_block;
-    int r1 = r0 + rows_per_block;
-    if (r1 > rows) r1 = rows;
-    float s = 0.f;
-    if (c < cols)
-        for (int r = r0 + ty; r < r1; r += 4) s += x[(size_t)r * cols + c];
-    red[ty][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (ty == 0 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 static int mk_lin(LinP& p, int kind, int in_f, int out_f, const float* const w[8]) {
@@ -337,10 +347,18 @@ extern "C" int seld_hc_linear_fwd(int32_t kind, int32_t rows, int32_t in_feature
     return check_launch();
 }
 
+// row splits of the weight / bias gradient: at most LIN_SPLITS partial results, added in order by the fold
+static constexpr int LIN_SPLITS = 8;
+static int lin_rows_per_split(int rows) {
+    int rps = (rows + LIN_SPLITS - 1) / LIN_SPLITS;
+    rps = (rps + 15) / 16 * 16;
+    return rps < 128 ? 128 : rps;
+}
+
 extern "C" size_t seld_hc_linear_bwd_workspace(int32_t kind, int32_t in_features, int32_t out_features) {
     (void)kind;
     if (in_features <= 0 || out_features <= 0) return 0;
-    return (size_t)in_features * out_features * sizeof(float);
+    return (size_t)LIN_SPLITS * ((size_t)in_features * out_features + out_features) * sizeof(float);
 }
 
 extern "C" int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_features, int32_t out_features, const float* x,
@@ -359,27 +377,29 @@ extern "C" int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_feature
         rc = check_launch();
         if (rc) return rc;
     }
-    if (dw) {
-        if (!x) return SELD_EINVAL;
+    if (dw || dbias) {
+        if (dw && !x) return SELD_EINVAL;
         if (!workspace || workspace_bytes < seld_hc_linear_bwd_workspace(kind, in_features, out_features)) return SELD_EWORKSPACE;
-        const int rps = env().deterministic ? rows : 128;       // one row range: a single contribution per element
-        dim3 grid((out_features + 63) / 64, (in_features + 63) / 64, (rows + rps - 1) / rps);
-        if (hipMemsetAsync(workspace, 0, (size_t)in_features * out_features * sizeof(float), st) != hipSuccess) return SELD_ELAUNCH;
-        hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, st, rows, rps, in_features, out_features, x, dy, (float*)workspace);
+        const int rps = lin_rows_per_split(rows);
+        const int nz = (rows + rps - 1) / rps;
+        float* dM = (float*)workspace;
+        float* dB = dM + (size_t)LIN_SPLITS * in_features * out_features;
+        if (dw) {
+            dim3 grid((out_features + 63) / 64, (in_features + 63) / 64, nz);
+            hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, st, rows, rps, in_features, out_features, x, dy, dM,
+                               dbias ? dB : (float*)nullptr);
+        } else {
+            // bias only: the column sums alone (x is not read: the first input tile of a one-column input)
+            dim3 grid((out_features + 63) / 64, 1, nz);
+            hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, st, rows, rps, 0, out_features, dy, dy, dM, dB);
+        }
         rc = check_launch();
         if (rc) return rc;
         WPtrsMut out{};
-        for (int i = 0; i < 8; ++i) out.p[i] = i < kind ? dw[i] : nullptr;
-        const int total = in_features * out_features / (kind == SELD_LIN_REAL ? 1 : kind);
-        hipLaunchKernelGGL(linear_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p, (const float*)workspace, out);
-        rc = check_launch();
-        if (rc) return rc;
-    }
-    if (dbias) {
-        const int rpb = env().deterministic ? rows : 64;
-        if (hipMemsetAsync(dbias, 0, (size_t)out_features * sizeof(float), st) != hipSuccess) return SELD_ELAUNCH;
-        hipLaunchKernelGGL(column_sum_kernel, dim3((out_features + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, st, dy, rows,
-                           out_features, rpb, dbias);
+        for (int i = 0; i < 8; ++i) out.p[i] = (dw && i < kind) ? dw[i] : nullptr;
+        const int total = in_features * out_features / (kind == SELD_LIN_REAL ? 1 : kind) + out_features;   // weights, then bias
+        hipLaunchKernelGGL(linear_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p, (const float*)dM, (const float*)dB, nz, out,
+                           dbias);
         rc = check_launch();
     }
     return rc;

@@ -752,6 +752,9 @@ __global__ void transpose_kernel(const float* __restrict__ x, int R, int Cc, flo
 // ------------------------------------------------------------------------------------------
 // loss = w_sed * mean BCE(sed, t_sed) + w_doa * mean MSE(doa, t_doa)     (train.py:186-204)
 // ------------------------------------------------------------------------------------------
+constexpr int LOSS_BLOCKS = 256;
+__device__ float g_loss_part[LOSS_BLOCKS];
+__device__ unsigned g_loss_ticket;          // zero at module load, handed back zero by every launch
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sed, const float* __restrict__ doa,
                                                    const float* __restrict__ target, long long rows, int n_sed, int n_doa,
                                                    float w_sed, float w_doa, float* __restrict__ loss,
@@ -779,9 +782,28 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sed
             if (ddoa) ddoa[o] = w_doa * inv_doa * 2.f * d;
         }
     }
-    float v[1] = {acc};
-    float* const dst[1] = {loss};
-    block_atomic<1>(v, dst);
+    // workgroup sums -> g_loss_part; the workgroup that draws the last ticket adds them in a fixed order and writes the
+    // loss: no zeroed accumulator (the host mirror used to launch a fill per step), the same bits for any grid
+    __shared__ float red[4];
+    __shared__ int last;
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        g_loss_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicAdd(&g_loss_ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    __threadfence();
+    float t = 0.f;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) t += *(volatile float*)&g_loss_part[b];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) {
+        *loss = t;
+        g_loss_ticket = 0;          // ready for the next evaluation (launches of this kernel on one device must not overlap)
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1128,7 +1150,7 @@ extern "C" int seld_loss_fwd_bwd(const float* sed, const float* doa, const float
                                  int32_t n_doa, float w_sed, float w_doa, float* loss, float* dsed, float* ddoa,
                                  void* stream) {
     if (!sed || !doa || !target || !loss || rows <= 0 || n_sed <= 0 || n_doa <= 0) return SELD_EINVAL;
-    hipLaunchKernelGGL(loss_kernel, dim3(env().deterministic ? 1u : grid_for(rows * (n_sed + n_doa), 256, 1024)), dim3(256), 0, ST(stream), sed, doa,
+    hipLaunchKernelGGL(loss_kernel, dim3(grid_for(rows * (n_sed + n_doa), 256, LOSS_BLOCKS)), dim3(256), 0, ST(stream), sed, doa,
                        target, (long long)rows, n_sed, n_doa, w_sed, w_doa, loss, dsed, ddoa);
     return check_launch();
 }

@@ -468,10 +468,19 @@ def _hcq_ok(desc, mode, npair=1):
 def _direct_targets(params, bias):
     """Gradient slots to accumulate into directly, or None.  A parameter opts in when its owner (FlatAdam)
     pre-attached `.grad` as a view of a flat buffer and set `_seld_direct_grad`."""
-    ts = list(params) + ([bias] if bias is not None else [])
+    ts = [getattr(t, "_seld_base_param", t) for t in params] + ([bias] if bias is not None else [])
     if all(getattr(t, "_seld_direct_grad", False) and t.grad is not None for t in ts):
-        return [t.grad for t in params], (bias.grad if bias is not None else None)
+        return [b.grad if b is t else b.grad.view(t.shape) for b, t in zip(ts, params)], (bias.grad if bias is not None else None)
     return None
+
+
+def as_conv_weight(param, shape):
+    """A contiguous reshape of a parameter used as a convolution weight (the attention's Linear applied as a 1x1
+    convolution, model.py:46): the view remembers its parameter, so the backward kernels write that parameter's gradient
+    slot directly instead of returning a tensor for autograd to add to it."""
+    w = param.view(shape)
+    w._seld_base_param = param
+    return w
 
 
 # ---- weight gradients on a second HIP stream -------------------------------------------------------------
@@ -1584,7 +1593,7 @@ class SeldLossFn(torch.autograd.Function):
         tgt = _req(target.reshape(-1, target.shape[-1]), "target")
         rows, n_sed = sed2.shape
         n_doa = doa2.shape[1]
-        loss = torch.zeros(1, device=sed.device, dtype=torch.float32)
+        loss = torch.empty(1, device=sed.device, dtype=torch.float32)       # written, not accumulated (ticketed reduction)
         dsed, ddoa = torch.empty_like(sed2), torch.empty_like(doa2)
         L.check(L.lib().seld_loss_fwd_bwd(L.ptr(sed2), L.ptr(doa2), L.ptr(tgt), ctypes.c_int64(rows), n_sed, n_doa,
                                           ctypes.c_float(w_sed), ctypes.c_float(w_doa), L.ptr(loss), L.ptr(dsed),
@@ -1763,10 +1772,13 @@ class HyperConvStatsFn(torch.autograd.Function):
         ctx.wt_ahead = _transpose_ahead(desc, ws) if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(x)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)        # no zero-filled "gradient" of the statistics buffer per backward pass
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        if dy is None:
+            return (None,) * (5 + len(ctx.w_params))
         dx, dbias, dws = _conv_backward(ctx, dy, 5)
         return (dx, dbias, None, None, None, *dws)
 
@@ -1776,22 +1788,31 @@ def hyper_conv_stats(x, ws, bias, stride, padding, dilation):
 
 
 class BnReluPoolFn(torch.autograd.Function):
-    """MaxPool2d(ph, pw)(ReLU(BatchNorm2d(y))) in one pass each way (model.py:278-281)."""
+    """[Dropout(drop_p)](MaxPool2d(ph, pw)(ReLU(BatchNorm2d(y)))) in one pass each way (model.py:278-282)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, ph, pw, stats, nbt):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, ph, pw, stats, nbt, drop_p):
         y = _req(y, "y")
         N, C, Hh, Ww = y.shape
         mean, invstd = bn_prepare(y, running_mean, running_var, training, momentum, eps, stats, nbt)
         pooled = torch.empty((N, C, Hh // ph, Ww // pw), device=y.device, dtype=torch.float32)
         idx = torch.empty(pooled.shape, device=y.device, dtype=torch.uint8)
-        L.check(L.lib().seld_bn_relu_pool_fwd(L.ptr(y), N, C, Hh, Ww, ph, pw, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-                                              L.ptr(beta), L.ptr(pooled), L.ptr(idx), L.current_stream()),
-                "seld_bn_relu_pool_fwd")
+        ctx.rng = None
+        out = None
+        p_, seed, off, state = 0.0, 0, 0, None
+        if drop_p > 0.0:           # same draw as a DropoutFn on `pooled` at this point
+            p_ = float(drop_p)
+            seed, off, state = philox.draw((pooled.numel() + 3) // 4, y.device)
+            out = torch.empty_like(pooled)
+            ctx.rng = (p_, seed, off, state)
+        L.check(L.lib().seld_bn_relu_pool_fwd_drop(L.ptr(y), N, C, Hh, Ww, ph, pw, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                                   L.ptr(beta), L.ptr(pooled), L.ptr(idx), ctypes.c_float(p_),
+                                                   ctypes.c_uint64(seed), ctypes.c_uint64(off), L.ptr(state), L.ptr(out),
+                                                   L.current_stream()), "seld_bn_relu_pool_fwd_drop")
         ctx.geom = (N, C, Hh, Ww, ph, pw, training)
         ctx.bn_params = (gamma, beta)
         ctx.save_for_backward(y, pooled, idx, mean, invstd)
-        return pooled
+        return pooled if out is None else out
 
     @staticmethod
     def backward(ctx, dpooled):
@@ -1802,14 +1823,17 @@ class BnReluPoolFn(torch.autograd.Function):
         slot, clean = _claim_grad_slots((gamma, beta))
         red = slot if clean else torch.zeros(2 * C, device=y.device, dtype=torch.float32)
         dy = torch.empty_like(y)
-        L.check(L.lib().seld_bn_relu_pool_bwd(L.ptr(dpooled), L.ptr(pooled), L.ptr(idx), L.ptr(y), N, C, Hh, Ww, ph, pw,
-                                              L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(training),
-                                              L.ptr(red), L.ptr(dy), L.current_stream()), "seld_bn_relu_pool_bwd")
+        p_, seed, off, state = ctx.rng if ctx.rng is not None else (0.0, 0, 0, None)
+        L.check(L.lib().seld_bn_relu_pool_bwd_drop(L.ptr(dpooled), L.ptr(pooled), L.ptr(idx), L.ptr(y), N, C, Hh, Ww, ph, pw,
+                                                   L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(training),
+                                                   L.ptr(red), L.ptr(dy), ctypes.c_float(p_), ctypes.c_uint64(seed),
+                                                   ctypes.c_uint64(off), L.ptr(state), L.current_stream()),
+                "seld_bn_relu_pool_bwd_drop")
         if slot is not None:
             if not clean:
                 axpy_(slot, red, 2 * C)     # one add into the flat gradient slice [dgamma | dbeta]
-            return (dy,) + (None,) * 11
-        return (dy, red[:C], red[C:]) + (None,) * 9
+            return (dy,) + (None,) * 12
+        return (dy, red[:C], red[C:]) + (None,) * 10
 
 
 def axpy_(dst_first, src, n):
@@ -1817,9 +1841,15 @@ def axpy_(dst_first, src, n):
     L.check(L.lib().seld_accumulate(L.ptr(dst_first), L.ptr(src), ctypes.c_int64(n), L.current_stream()), "seld_accumulate")
 
 
-def bn_relu_pool(y, bn, ph, pw, stats=None):
-    return BnReluPoolFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
-                              bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(ph), int(pw), stats, _nbt(bn))
+def bn_relu_pool(y, bn, ph, pw, stats=None, drop_p=0.0):
+    """drop_p > 0 (training): the stage's Dropout rides in the same kernels when the shape allows, else it follows."""
+    drop_p = float(drop_p) if bn.training else 0.0
+    fuse = drop_p > 0.0 and bool(L.lib().seld_bn_relu_pool_drop_ok(int(y.shape[2]), int(y.shape[3]), int(ph), int(pw)))
+    out = BnReluPoolFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
+                             bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(ph), int(pw), stats, _nbt(bn),
+                             drop_p if fuse else 0.0)
+    return out if fuse or drop_p == 0.0 else dropout(out, drop_p, True)
+
 
 class ConvBnReluPoolFn(torch.autograd.Function):
     """pooled = MaxPool2d(ph, 1)(ReLU(BatchNorm2d(W (x) x))) for a convolution whose INPUT needs no gradient -- the first
@@ -1837,10 +1867,11 @@ class ConvBnReluPoolFn(torch.autograd.Function):
         k = tuple(ws[0].shape[2:])
         desc = make_conv_desc(tuple(x.shape), ws[0].shape[0] * algebra, algebra, k, stride, padding, dilation)
         x = _req(x, "x")
-        stats = new_stats(desc.Cout, x.device) if training else None
         wp = hcq_weights.get(desc, 2, ws) if (ph == 8 and algebra > 1) else None
+        nostore = wp is not None and training and _first_stage_nostore(desc)
+        stats = new_stats(desc.Cout, x.device) if training and not nostore else None
         ctx.gram = None
-        if wp is not None and training and _first_stage_nostore(desc):
+        if nostore:
             # no convolution output at all (csrc/first_stage.hip): BatchNorm's statistics from the input's second moments,
             # the pooling convolution writes the window value + row only, the backward pass works from those and x
             lib = L.lib()
@@ -2041,4 +2072,4 @@ def conv_bn_relu_pool(x, ws, bias, bn, ph, pw, stride, padding, dilation, drop_p
         y, stats = hyper_conv_stats(x, ws, bias, stride, padding, dilation)
     else:
         y, stats = hyper_conv(x, ws, bias, stride, padding, dilation), None
-    return dropout(bn_relu_pool(y, bn, ph, pw, stats), drop_p, bn.training)
+    return bn_relu_pool(y, bn, ph, pw, stats, drop_p)

@@ -79,7 +79,8 @@ class MultiHeadAttention(nn.Module):
         v, k, q = self.values(v), self.keys(k), self.queries(q)
         out = H.mha_core(q, k, v, self.num_heads)
         # fc_out on the (N, E, T) layout = 1x1 convolution with the Linear's (E, E) weight
-        return H.hyper_conv(out, (self.fc_out.weight.unsqueeze(-1),), self.fc_out.bias, 1, 0, 1)
+        w = self.fc_out.weight
+        return H.hyper_conv(out, (H.as_conv_weight(w, (*w.shape, 1)),), self.fc_out.bias, 1, 0, 1)
 
     def forward_nct(self, x):
         return self._attend(x, x, x)

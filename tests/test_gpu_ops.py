@@ -706,3 +706,125 @@ def test_first_stage_full_size_without_conv_output(monkeypatch):
         assert 0.3 < float(kept.float().mean()) < 0.8
         err = ((got * 0.7 - zr) * kept).abs().max()                            # kept elements carry z / (1 - p)
         assert float(err) <= 2e-4 * float(zr.abs().max()), (n, float(err))
+
+
+# ------------------------------------------------------------------------------------------
+# round-3 launch diet: linear backward without zero-fills / atomics, loss without a pre-zeroed scalar, the later CNN
+# stages' Dropout inside the BN+ReLU+MaxPool passes
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,fin,fout,rows", [(1, 384, 42, 5), (1, 70, 126, 130), (1, 384, 384, 2049), (8, 384, 384, 16384),
+                                                (4, 64, 128, 1000)])
+def test_linear_backward_row_splits(kind, fin, fout, rows):
+    """seld_hc_linear_bwd: x^T dy and the column sums of dy in up to 8 row splits, plain stores + an ordered fold
+    (csrc/linear.hip) -- against fp64 on row counts below one split, ragged, and far beyond 8 x 128; run twice on a dirty
+    workspace: the same bits (nothing depends on the workspace's previous contents, nothing is accumulated atomically)."""
+    P = pkg()
+    H, L = P.hip_ops, P._lib
+    import ctypes
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(rows, fin, generator=gen)
+    dy = torch.randn(rows, fout, generator=gen)
+    if kind == 1:
+        ws = [torch.randn(fout, fin, generator=gen) * 0.1]
+    else:
+        ws = [torch.randn(fin // kind, fout // kind, generator=gen) * 0.1 for _ in range(kind)]
+    xd, dyd, wd = x.to(DEV), dy.to(DEV), [w.to(DEV) for w in ws]
+    lib = L.lib()
+    lib.seld_hc_linear_bwd_workspace.restype = ctypes.c_size_t
+    nbytes = lib.seld_hc_linear_bwd_workspace(kind, fin, fout)
+
+    def run(fill, with_w=True):
+        wsb = torch.full(((nbytes + 3) // 4,), fill, device=DEV)
+        dws = [torch.full_like(w, 7.0) for w in wd]
+        db = torch.full((fout,), 7.0, device=DEV)
+        L.check(lib.seld_hc_linear_bwd(kind, rows, fin, fout, L.ptr(xd), L.ptr(dyd), L.ptr_array8(wd), None,
+                                       L.ptr_array8(dws) if with_w else None, L.ptr(db), L.ptr(wsb), ctypes.c_size_t(nbytes),
+                                       L.current_stream()), "seld_hc_linear_bwd")
+        torch.cuda.synchronize()
+        return dws, db
+
+    (dw1, db1), (dw2, db2) = run(0.0), run(float("nan"))
+    for a, b in zip(dw1, dw2):
+        assert torch.equal(a, b)
+    assert torch.equal(db1, db2)
+    _, db3 = run(3.0, with_w=False)                       # bias gradient alone
+    assert torch.equal(db3, db1)
+    x64 = x.double()
+    w64 = [w.double().requires_grad_(True) for w in ws]
+    b64 = torch.zeros(fout, dtype=torch.float64, requires_grad=True)
+    if kind == 1:
+        yr = F.linear(x64, w64[0], b64)
+    else:
+        yr = O.dual_quaternion_linear(x64, w64, b64) if kind == 8 else O.quaternion_linear(x64, *w64, b64)
+    (yr * dy.double()).sum().backward()
+    for i, (a, b) in enumerate(zip(dw1, w64)):
+        _close(a, b.grad, rel=1e-4, what=f"dw{i}")
+    _close(db1, b64.grad, rel=1e-4, what="dbias")
+
+
+def test_loss_needs_no_zeroed_scalar_and_repeats_bit_for_bit():
+    """seld_loss_fwd_bwd WRITES the loss (ticketed ordered reduction, csrc/nn_ops.hip): a poisoned output buffer, many
+    evaluations back to back, sizes from one workgroup to the 256-workgroup cap."""
+    P = pkg()
+    L = P._lib
+    import ctypes
+    lib = L.lib()
+    for rows in (3, 700, 40000):
+        gen = torch.Generator().manual_seed(rows)
+        sed = torch.rand(rows, 42, generator=gen).clamp(1e-4, 1 - 1e-4)
+        doa = torch.rand(rows, 126, generator=gen) * 2 - 1
+        tgt = torch.cat(((torch.rand(rows, 42, generator=gen) < 0.1).float(), torch.rand(rows, 126, generator=gen) * 2 - 1), 1)
+        a, b, t = sed.to(DEV), doa.to(DEV), tgt.to(DEV)
+        outs = []
+        for k in range(6):
+            loss = torch.full((1,), float("nan") if k % 2 else 1e9, device=DEV)
+            L.check(lib.seld_loss_fwd_bwd(L.ptr(a), L.ptr(b), L.ptr(t), ctypes.c_int64(rows), 42, 126, ctypes.c_float(1.0),
+                                          ctypes.c_float(5.0), L.ptr(loss), None, None, L.current_stream()), "seld_loss_fwd_bwd")
+            outs.append(loss)
+        torch.cuda.synchronize()
+        vals = [float(o.item()) for o in outs]
+        assert all(v == vals[0] for v in vals), vals
+        ref = O.seld_loss(sed.double()[None], doa.double()[None], tgt.double()[None], 42, 1.0, 5.0)
+        assert abs(vals[0] - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+
+
+@pytest.mark.parametrize("shape,ph", [((2, 192, 16, 64), 8), ((3, 16, 4, 40), 2), ((2, 8, 12, 32), 3)])
+def test_bn_relu_pool_with_the_stage_dropout_inside(shape, ph):
+    """bn_relu_pool(..., drop_p) (seld_bn_relu_pool_fwd_drop / _bwd_drop: CNN stages 2 and 3, model.py:278-282) against
+    bn_relu_pool followed by a separate dropout at the same Philox offset: same mask, same output, same gradients, the
+    same number of draws."""
+    P = pkg()
+    H = P.hip_ops
+    gen = torch.Generator().manual_seed(41)
+    y0 = torch.randn(*shape, generator=gen)
+    C = shape[1]
+    g0, b0 = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.1
+    cot = torch.randn(shape[0], C, shape[2] // ph, shape[3], generator=gen)
+
+    def run(inside):
+        bn = P.hip_nn.BatchNorm2d(C).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(g0.to(DEV)); bn.bias.copy_(b0.to(DEV))
+        y = y0.to(DEV).requires_grad_(True)
+        H.philox.set_offset(5000)
+        if inside:
+            out = H.bn_relu_pool(y, bn, ph, 1, None, 0.3)
+        else:
+            out = H.dropout(H.bn_relu_pool(y, bn, ph, 1, None), 0.3, True)
+        (out * cot.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().cpu(), y.grad.cpu(), bn.weight.grad.cpu(), bn.bias.grad.cpu(), H.philox.offset
+
+    got, ref = run(True), run(False)
+    assert got[4] == ref[4]
+    zero = ref[0] == 0
+    assert 0.3 < float(zero.float().mean()) < 0.95
+    assert torch.equal(got[0], ref[0])
+    _close(got[1], ref[1], rel=1e-5, what="dy")
+    _close(got[2], ref[2], rel=1e-4, what="dgamma")
+    _close(got[3], ref[3], rel=1e-4, what="dbeta")
+    # eval mode: no dropout, nothing drawn
+    bn = P.hip_nn.BatchNorm2d(C).to(DEV).eval()
+    H.philox.set_offset(0)
+    out = H.bn_relu_pool(y0.to(DEV), bn, ph, 1, None, 0.3)
+    assert H.philox.offset == 0 and out.shape == cot.shape
