@@ -308,6 +308,15 @@ int seld_gate_bwd_apply(const float* dy, const float* yf, const float* yg, int32
 int seld_hcq_first_pool(const seld_conv_desc* desc, const float* x, const float* wpack, const float* bias,
                         const float* gamma, int32_t want_stats, float* y, float* stats, float* pool_raw, uint8_t* idx,
                         void* stream);
+/* The same pooling convolution when BatchNorm's statistics are known BEFORE it runs (seld_first_stage_bn): no y, no
+ * statistics, and BatchNorm + ReLU + the stage's Dropout (model.py:279-282) are applied to the window value in the
+ * epilogue: out = Dropout(relu(a raw + b)) with the mask seld_dropout_fwd draws for (seed, offset, state) on `out`
+ * (drop_p = 0: none).  idx as above; pool_raw (same size, must be allocated) is written ONLY for channels with
+ * gamma == 0 -- the one case in which seld_first_stage_bwd cannot recover xhat from out. */
+int seld_hcq_first_pool_bn(const seld_conv_desc* desc, const float* x, const float* wpack, const float* bias,
+                           const float* gamma, const float* beta, const float* mean, const float* invstd,
+                           float drop_p, uint64_t seed, uint64_t offset, const uint64_t* state, float* pool_raw,
+                           uint8_t* idx, float* out, void* stream);
 /* out (nullable) = Dropout(p)(pooled) in the same pass, the mask seld_dropout_fwd would draw for (seed, offset, state) */
 /* ------------------------------------------------------------------------------------------
  * First stage without its convolution output (csrc/first_stage.hip): conv3x3 on the 8-channel network input ->
@@ -315,7 +324,7 @@ int seld_hcq_first_pool(const seld_conv_desc* desc, const float* x, const float*
  * the input, so BatchNorm's statistics follow from the input's second moments (gram: 80 x 80 doubles, [G; s], count at
  * [72][72]) and the weights, and the backward pass needs the pooled-size tensors and x only.
  *   forward : seld_first_stage_gram -> seld_first_stage_bn (mean, invstd, running statistics, W G) ->
- *             seld_hcq_first_pool with y = NULL (window value + row) -> seld_bn_pool_finish
+ *             seld_hcq_first_pool_bn (the stage's output + window row; three launches + two small folds in all)
  *   backward: seld_first_stage_bwd (dgamma, dbeta, component weight gradients; reproducible: no atomics)
  * Shapes: Cin = 8, 3x3 'same' stride 1, H % 8 == 0, W % 64 == 0 (backward: Cout in {64, 128, 192}; 64 only for algebra 1 / 4); workspace queries
  * return 0 otherwise. */

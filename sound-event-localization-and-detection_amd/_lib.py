@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libseld_hip.so")
+# SELD_HIP_LIB: another build of the same library (tools/hcq_ablate.sh timing variants); there is still no fallback
+LIB_PATH = os.environ.get("SELD_HIP_LIB") or os.path.join(_HERE, "csrc", "libseld_hip.so")
 
 SELD_OK = 0
 _ERRORS = {-1: "SELD_EINVAL", -2: "SELD_EWORKSPACE", -3: "SELD_ELAUNCH", -4: "SELD_EUNSUPPORTED"}

@@ -13,8 +13,9 @@
 //     15 tiles of 16 x 16 per 4 positions), fs_gram_fold_kernel adds the workgroups' partials in double precision in a fixed
 //     order, fs_bn_from_gram_kernel evaluates the two forms above in double and finishes mean / invstd / running
 //     statistics exactly as seld_bn_finalize_ex does.
-//   * The pooling convolution (csrc/hcq_conv.hip, hcq_first_pool_kernel) then runs with y and its statistics switched off:
-//     it writes the window's raw value and row only (pooled size).
+//   * The pooling convolution (csrc/hcq_conv.hip, hcq_first_pool_kernel<.., FIN>) then runs with y and its statistics
+//     switched off and finishes the stage in its epilogue: relu(a v + b) and the Dropout on the window value -- the stage's
+//     output and the window row are all it writes (pooled size; the raw value only for channels with gamma == 0).
 //   * Backward, the gradient w.r.t. y is dy = c1 y + a dz + c0 per channel (BatchNorm backward; dz = the pooled gradient at
 //     the window's arg-max row where ReLU is open, 0 elsewhere), so the weight gradient of the real matrix is
 //         dW_c = c1_c (W G)_c  +  c0_c s  +  a_c sum_pos dz_c(pos) xcol(pos)
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void fs_bn_from_gram_kernel(const FsBnP p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward: per-channel reductions over the pooled-size tensors, reproducible (chunk partials + ordered sum)
-//   dz = dout * scale * [out != 0]      xhat = (raw - mean) invstd       v0 = sum dz xhat, v1 = sum dz
+//   dz = dout * scale * [out != 0]      xhat = (out / scale - beta) / gamma       v0 = sum dz xhat, v1 = sum dz
 // (out = relu(a raw + b) * mask * scale is non-zero exactly where ReLU is open AND the Dropout kept the element: the
 // stage's own output replays both decisions, no random numbers are redrawn)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -247,6 +248,11 @@ struct FsRedP {
 __global__ __launch_bounds__(256) void fs_reduce_kernel(const FsRedP p) {
     const int c = blockIdx.y, chunk = blockIdx.x;
     const float mu = p.mean[c], is = p.invstd[c];
+    // xhat from the stage's output: out / scale = gamma xhat + beta wherever out != 0; only a channel with gamma == 0 needs
+    // the raw window value (the one case seld_hcq_first_pool_bn writes it for)
+    const float ga = p.gamma[c], be = p.beta[c];
+    const bool degenerate = ga == 0.f;
+    const float inv_g = degenerate ? 0.f : 1.0f / ga, inv_scale = 1.0f / p.scale;
     const long long total = (long long)p.N * p.S;                 // elements of this channel, S % 4 == 0
     const long long per = ((total / 4 + p.nchunk - 1) / p.nchunk) * 4;
     const long long beg = (long long)chunk * per;
@@ -256,7 +262,8 @@ __global__ __launch_bounds__(256) void fs_reduce_kernel(const FsRedP p) {
     for (long long k = beg + threadIdx.x * 4; k < end; k += 256 * 4) {
         const long long n = k / p.S;
         const size_t off = ((size_t)n * p.C + c) * p.S + (size_t)(k - n * p.S);
-        const float4 r4 = *reinterpret_cast<const float4*>(p.raw + off);
+        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (degenerate) r4 = *reinterpret_cast<const float4*>(p.raw + off);
         const float4 d4 = *reinterpret_cast<const float4*>(p.dout + off);
         const float4 o4 = *reinterpret_cast<const float4*>(p.out + off);
         const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w}, oo[4] = {o4.x, o4.y, o4.z, o4.w};
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256) void fs_reduce_kernel(const FsRedP p) {
         for (int e = 0; e < 4; ++e)
             if (oo[e] != 0.f) {
                 const float dz = dd[e] * p.scale;
-                v0 += dz * ((rr[e] - mu) * is);
+                v0 += dz * (degenerate ? (rr[e] - mu) * is : (oo[e] * inv_scale - be) * inv_g);
                 v1 += dz;
             }
     }
@@ -621,7 +628,8 @@ extern "C" size_t seld_first_stage_bwd_workspace(const seld_conv_desc* d) {
 
 /* Backward pass of the first stage (training mode, batch statistics) WITHOUT the convolution output:
  *   dout (N, Cout, H/8, W) gradient w.r.t. the stage's output `out` (= relu(a raw + b) * Dropout mask / (1 - drop_p); its
- *   zeros replay ReLU and the Dropout, drop_p = 0: none); raw / idx as written by seld_hcq_first_pool; mean / invstd from
+ *   zeros replay ReLU and the Dropout, drop_p = 0: none); raw / idx as written by seld_hcq_first_pool[_bn] (raw is READ only
+ *   for channels with gamma == 0: everywhere else xhat comes back from out); mean / invstd from
  *   seld_first_stage_bn, wg = W G from there, gram from seld_first_stage_gram; bias: the convolution's (nullable).
  * Adds the BatchNorm weight / bias gradients to dgamma / dbeta and the convolution's component weight gradients to dw[c]
  * (torch autograd through model.py:273-283 in the reference).  No atomics: reproducible. */

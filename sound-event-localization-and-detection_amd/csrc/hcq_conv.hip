@@ -33,6 +33,13 @@
 #include <type_traits>
 #include "hc_common.h"
 
+// Phase ablation for timing experiments only (tools/hcq_ablate.sh builds variants into tools/_bin; results are WRONG with
+// any bit set): 1 = weight fragments loaded once, 2 = LDS operand reads + sums once, 4 = input staged once,
+// 8 = no per-chunk barrier.  The shipped library is built with 0.
+#ifndef HCQ_DBG
+#define HCQ_DBG 0
+#endif
+
 namespace seld {
 
 struct HcqP {
@@ -213,13 +220,16 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     float raw[4];
     constexpr int NPC = NR * NPAIR;                          // fragment pairs per chunk
 
+    bool dbg_started = false;
     auto load_b1 = [&](const float* blk, int j, int m, auto ntrc) __attribute__((always_inline)) {
         constexpr int NTR = decltype(ntrc)::value;
+        if ((HCQ_DBG & 1) && dbg_started) return;
         const float* q = blk + ((long long)(j * 8 + m) * 64 + lane) * (2 * NTR);
 #pragma unroll
         for (int t = 0; t < NTR; ++t) bfr[m][t] = *reinterpret_cast<const float2*>(q + 2 * t);
     };
     auto read_raw = [&](const float* xs, int g) __attribute__((always_inline)) {
+        if ((HCQ_DBG & 2) && dbg_started) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) raw[q] = xs[aoff[g] + q * comp_stride];
     };
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunks) load_x();
+        if (ch + 1 < nchunks && !(HCQ_DBG & 4)) load_x();
         const float* xb = lds + buf * buf_floats;
         const float* wc = wbase + (long long)ch * chunk_stride;
         const bool more = ch + 1 < nchunks;
@@ -245,7 +255,9 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
         const float* xs0 = xb + p.half_src[0] * 4 * comp_stride;
         const float* xs1 = xb + p.half_src[1] * 4 * comp_stride;
         read_raw(xs0, 0);
-        xforms(raw, gm[0]);
+        if (!(HCQ_DBG & 2) || !dbg_started) xforms(raw, gm[0]);
+        if ((HCQ_DBG & 2) && !dbg_started) xforms(raw, gm[1]);
+        dbg_started = true;
 #pragma unroll
         for (int s = 0; s < NR * NG; ++s) {                   // k-groups of the chunk, both ranges
             const int r = s / NG, g = s - r * NG;
@@ -282,11 +294,11 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
                     }
                 }
             }
-            if (!last) xforms(raw, gm[gst ^ 1]);
+            if (!last && !(HCQ_DBG & 2)) xforms(raw, gm[gst ^ 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (ch + 1 < nchunks) store_x(buf ^ 1);
-        __syncthreads();
+        if (ch + 1 < nchunks && !(HCQ_DBG & 4)) store_x(buf ^ 1);
+        if (!(HCQ_DBG & 8)) __syncthreads();
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
@@ -625,12 +637,21 @@ struct HcqPoolP {
     const float* gamma;          // (Cdst)
     float* pool_raw;             // (N, Cdst, Himg / 8, W): the conv output at the window's arg-max / arg-min row
     unsigned char* idx;          // same shape: that row (0..7)
+    // FIN: BatchNorm with KNOWN statistics (first_stage.hip: from the input's second moments), ReLU and the stage's Dropout
+    // applied to the window value before it is stored: out = relu(a raw + b) * mask; pool_raw is then written only for
+    // channels with gamma == 0 (the one case in which the backward pass cannot recover xhat from out)
+    const float* beta;
+    const float* mean;
+    const float* invstd;
+    float* out;
+    DropP drop;
 };
 
 // WY = false: y is not written and no statistics are gathered (csrc/first_stage.hip: the statistics come from the input's
 // second moments, the backward pass never reads y) -- the kernel's only output is the pooled-size window value + row.
-template <int IBC, int NT1, int NT2, int NR, int R, bool WY>
+template <int IBC, int NT1, int NT2, int NR, int R, bool WY, bool FIN = false>
 __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, const HcqPoolP pp) {
+    static_assert(!(WY && FIN), "the finishing variant knows the statistics beforehand: it never writes y");
     constexpr int KH = 3, KW = 3, TAPS = 9;
     constexpr int NT = NT1 + NT2;
     constexpr int KQ = IBC * TAPS;
@@ -822,8 +843,31 @@ __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, co
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned po = pool_off + (unsigned)(chb + q * p.OB) * PS;
-                *reinterpret_cast<float4*>(pp.pool_raw + po) = make_float4(yb[q][0], yb[q][1], yb[q][2], yb[q][3]);
                 *reinterpret_cast<unsigned*>(pp.idx + po) = bi[q];
+                if constexpr (FIN) {
+                    const int chn = chb + q * p.OB;
+                    const float gq = pp.gamma[chn];
+                    const float a = gq * pp.invstd[chn], bb = pp.beta[chn] - pp.mean[chn] * a;
+                    float z[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = yb[q][e];
+                        z[e] = fmaxf(v * a + bb, 0.f);
+                        if (v != v) z[e] = v;                                   // NaN propagates (torch's relu / max_pool)
+                    }
+                    if (pp.drop.p > 0.f) {       // the mask seld_dropout_fwd draws for element group po / 4 of `out`
+                        const uint64_t off = pp.drop.offset + (pp.drop.state ? pp.drop.state[0] : 0ull);
+                        const float4 mk = dropout_mask4(off + (uint64_t)(po >> 2), pp.drop.seed, pp.drop.p, pp.drop.scale);
+                        z[0] = mk.x != 0.f ? z[0] * mk.x : 0.f;
+                        z[1] = mk.y != 0.f ? z[1] * mk.y : 0.f;
+                        z[2] = mk.z != 0.f ? z[2] * mk.z : 0.f;
+                        z[3] = mk.w != 0.f ? z[3] * mk.w : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(pp.out + po) = make_float4(z[0], z[1], z[2], z[3]);
+                    if (gq == 0.f) *reinterpret_cast<float4*>(pp.pool_raw + po) = make_float4(yb[q][0], yb[q][1], yb[q][2], yb[q][3]);
+                } else {
+                    *reinterpret_cast<float4*>(pp.pool_raw + po) = make_float4(yb[q][0], yb[q][1], yb[q][2], yb[q][3]);
+                }
             }
         }
         if (want_stats) {
@@ -1328,16 +1372,13 @@ extern "C" int seld_hcq_conv(const seld_conv_desc* d, int32_t mode, int32_t npai
  * seld_first_stage_* path), the BatchNorm statistics (want_stats), and per pooling window
  * the raw value at the row that will be the maximum after BatchNorm + ReLU (by the sign of gamma) and that row.
  * wpack: seld_hcq_pack(desc, mode 2).  Follow with seld_bn_finalize_ex and seld_bn_pool_finish. */
-extern "C" int seld_hcq_first_pool(const seld_conv_desc* d, const float* x, const float* wpack, const float* bias,
-                                   const float* gamma, int32_t want_stats, float* y, float* stats, float* pool_raw,
-                                   uint8_t* idx, void* stream) {
-    if (hc_validate(d) != SELD_OK || !x || !wpack || !gamma || !pool_raw || !idx || (want_stats && (!stats || !y))) return SELD_EINVAL;
+static int hcq_first_pool_impl(const seld_conv_desc* d, const float* x, const float* wpack, const float* bias,
+                               int32_t want_stats, float* y, float* stats, const HcqPoolP& pp, bool fin, void* stream) {
     HcqPlan pl = hcq_plan(d, 2, 1);
     HcqKern k;
     if (!pl.ok || !hcq_pick(pl, &k) || pl.first_rows != 8) return SELD_EUNSUPPORTED;
     pl.kp.src = x; pl.kp.src2 = nullptr; pl.kp.wpack = wpack;
     pl.kp.dst[0] = y; pl.kp.bias[0] = bias; pl.kp.epilogue[0] = want_stats ? SELD_EPI_STATS : 0; pl.kp.stats[0] = stats;
-    const HcqPoolP pp{gamma, pool_raw, idx};
     const int NT = pl.NT1 + pl.NT2;
     const int npair = ((pl.IBC * 9 + 3) / 4 + 1) / 2;
     const size_t smem = ((size_t)pl.kp.A * pl.IBC * 10 * 72 + (size_t)NT * 4 * 4 * 16 * 2 +
@@ -1345,7 +1386,8 @@ extern "C" int seld_hcq_first_pool(const seld_conv_desc* d, const float* x, cons
     hipStream_t st = (hipStream_t)stream;
 #define SELD_FP(IBC_, NT1_, NT2_, NR_)                                                                                  \
     do {                                                                                                                \
-        auto kern = y ? hcq_first_pool_kernel<IBC_, NT1_, NT2_, NR_, 8, true> : hcq_first_pool_kernel<IBC_, NT1_, NT2_, NR_, 8, false>; \
+        auto kern = fin ? hcq_first_pool_kernel<IBC_, NT1_, NT2_, NR_, 8, false, true>                                  \
+                        : (y ? hcq_first_pool_kernel<IBC_, NT1_, NT2_, NR_, 8, true> : hcq_first_pool_kernel<IBC_, NT1_, NT2_, NR_, 8, false>); \
         if (smem > 64 * 1024 &&                                                                                         \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return SELD_ELAUNCH;                                                                                        \
@@ -1359,4 +1401,23 @@ extern "C" int seld_hcq_first_pool(const seld_conv_desc* d, const float* x, cons
     if (k.NR == 2) { if (k.NT2 == 2) SELD_FP(2, 1, 2, 2); else SELD_FP(2, 1, 1, 2); }
     if (k.NT1 == 2) SELD_FP(2, 2, 0, 1); else SELD_FP(2, 1, 0, 1);
 #undef SELD_FP
+}
+
+extern "C" int seld_hcq_first_pool(const seld_conv_desc* d, const float* x, const float* wpack, const float* bias,
+                                   const float* gamma, int32_t want_stats, float* y, float* stats, float* pool_raw,
+                                   uint8_t* idx, void* stream) {
+    if (hc_validate(d) != SELD_OK || !x || !wpack || !gamma || !pool_raw || !idx || (want_stats && (!stats || !y))) return SELD_EINVAL;
+    const HcqPoolP pp{gamma, pool_raw, idx, nullptr, nullptr, nullptr, nullptr, DropP{0.f, 1.f, 0, 0, nullptr}};
+    return hcq_first_pool_impl(d, x, wpack, bias, want_stats, y, stats, pp, false, stream);
+}
+
+extern "C" int seld_hcq_first_pool_bn(const seld_conv_desc* d, const float* x, const float* wpack, const float* bias,
+                                      const float* gamma, const float* beta, const float* mean, const float* invstd,
+                                      float drop_p, uint64_t seed, uint64_t offset, const uint64_t* state, float* pool_raw,
+                                      uint8_t* idx, float* out, void* stream) {
+    if (hc_validate(d) != SELD_OK || !x || !wpack || !gamma || !beta || !mean || !invstd || !pool_raw || !idx || !out ||
+        drop_p < 0.f || drop_p >= 1.f)
+        return SELD_EINVAL;
+    const HcqPoolP pp{gamma, pool_raw, idx, beta, mean, invstd, out, DropP{drop_p, 1.0f / (1.0f - drop_p), seed, offset, state}};
+    return hcq_first_pool_impl(d, x, wpack, bias, 0, nullptr, nullptr, pp, true, stream);
 }

@@ -1877,7 +1877,7 @@ class ConvBnReluPoolFn(torch.autograd.Function):
             lib = L.lib()
             o = conv_out_shape(desc)
             N, C, Hh, Ww = _y_shape(desc, o)
-            stage_timer = _Timed(desc, 0, label="first_stage_fwd(gram+bn+pool_conv+finish)" if kernel_timer.active else None)
+            stage_timer = _Timed(desc, 0, label="first_stage_fwd(gram+bn+finishing_pool_conv)" if kernel_timer.active else None)
             stage_timer.__enter__()
             gws = torch.empty(_fs_bytes(desc, "gram"), device=x.device, dtype=torch.uint8)
             L.check(lib.seld_first_stage_gram(ctypes.byref(desc), L.ptr(x), L.ptr(gws), ctypes.c_size_t(gws.numel()),
@@ -1889,29 +1889,23 @@ class ConvBnReluPoolFn(torch.autograd.Function):
                                             L.ptr(gws), ctypes.c_float(eps), ctypes.c_float(momentum), L.ptr(mean),
                                             L.ptr(invstd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), L.ptr(wg),
                                             L.current_stream()), "seld_first_stage_bn")
+            # raw: written (and read by the backward pass) only for channels with gamma == 0; untouched memory otherwise
             raw = torch.empty((N, C, Hh // ph, Ww), device=x.device, dtype=torch.float32)
             idx = torch.empty(raw.shape, device=x.device, dtype=torch.uint8)
-            L.check(lib.seld_hcq_first_pool(ctypes.byref(desc), L.ptr(x), L.ptr(wp), L.ptr(_req(bias, "bias")),
-                                            L.ptr(gamma), 0, None, None, L.ptr(raw), L.ptr(idx), L.current_stream()),
-                    "seld_hcq_first_pool")
+            result = torch.empty_like(raw)
             p_, seed, off, state = 0.0, 0, 0, None
-            pooled, out = None, None
             if drop_p > 0.0:
                 p_ = float(drop_p)
                 seed, off, state = philox.draw((raw.numel() + 3) // 4, x.device)
-                out = torch.empty_like(raw)
                 ctx.rng = (p_, seed, off, state)
-            else:
-                pooled = torch.empty_like(raw)
-            L.check(lib.seld_bn_pool_finish(L.ptr(raw), N, C, (Hh // ph) * Ww, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-                                            L.ptr(beta), L.ptr(pooled), ctypes.c_float(p_), ctypes.c_uint64(seed),
-                                            ctypes.c_uint64(off), L.ptr(state), L.ptr(out), L.current_stream()),
-                    "seld_bn_pool_finish")
+            L.check(lib.seld_hcq_first_pool_bn(ctypes.byref(desc), L.ptr(x), L.ptr(wp), L.ptr(_req(bias, "bias")), L.ptr(gamma),
+                                               L.ptr(beta), L.ptr(mean), L.ptr(invstd), ctypes.c_float(p_), ctypes.c_uint64(seed),
+                                               ctypes.c_uint64(off), L.ptr(state), L.ptr(raw), L.ptr(idx), L.ptr(result),
+                                               L.current_stream()), "seld_hcq_first_pool_bn")
             stage_timer.__exit__(None, None, None)
             ctx.desc, ctx.geom = desc, (N, C, Hh, Ww, ph, training)
             ctx.params = (ws, bias, gamma, beta)
             ctx.gram = (gws, wg)
-            result = pooled if out is None else out
             ctx.save_for_backward(x, raw, idx, mean, invstd, result)      # the output's zeros replay ReLU + Dropout backward
             return result
         if wp is not None:
