@@ -36,6 +36,13 @@
 // Phase ablation for timing experiments only (tools/hcq_ablate.sh builds variants into tools/_bin; results are WRONG with
 // any bit set): 1 = weight fragments loaded once, 2 = LDS operand reads + sums once, 4 = input staged once,
 // 8 = no per-chunk barrier.  The shipped library is built with 0.
+// Round-3 readings on cnn.1 (forward / data gradient, us): as shipped 774 / 732; 1: 636 / 591; 4: 718 / 668; 8: no change;
+// 1+2+4: 550 / 517 (the MFMA floor is 481).  The fragment loads are the largest term, and it is not their bytes, their
+// request count or their latency window that costs: loading the 4 raw components per (pair, tile) and forming the 8 sums
+// in registers (half the bytes and requests, two register stages = a whole pair of k-groups ahead) ran 773 / 745, with
+// three-wave occupancy lost on the TCN layers (177 VGPRs); rotating the chunk order per workgroup (so that workgroups in
+// step do not ask the L2 for the same lines) 751 / 723 against 752 / 722; staging the input from cache-resident
+// addresses 712 against 723.  Left as it is.
 #ifndef HCQ_DBG
 #define HCQ_DBG 0
 #endif
@@ -1123,9 +1130,11 @@ static HcqPlan hcq_plan(const seld_conv_desc* d, int mode, int npair) {
             k.tile_half[2][1] = both; k.tile_ob[2][1] = OB - 8;
             // 24 block channels: either ONE workgroup per position tile with three tiles (24 accumulators, the input
             // staged once: cnn.1 949 us against 1139), or the mixed tile in workgroups of its own (twice the
-            // workgroups for layers with few position tiles: TCN data gradient 47.5 us against 68.6)
+            // workgroups for layers with few position tiles: TCN data gradient 47.5 us against 68.6).  A forward PAIR
+            // brings its own factor of two (two weight sets): skip || residual at batch 32 (256 position tiles) 39.8 ->
+            // 32.3 us as 512 three-tile workgroups instead of 1024 two-tile ones, a third of them half padding
             const long long ptiles = (long long)d->N * Himg * W / 64;
-            if (OB == 24 && ptiles >= 512) { NT2 = 2; ob_step = 0; }
+            if (OB == 24 && ptiles * nsets >= 512) { NT2 = 2; ob_step = 0; }
             else mix = 1;
         }
         if (nreg == 0) return pl;
