@@ -477,6 +477,15 @@ size_t seld_mha_bwd_workspace(int32_t N, int32_t T, int32_t H);
 int seld_mha_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                  const float* lse, int32_t N, int32_t T, int32_t H, int32_t hd,
                  float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, void* stream);
+/* Self-attention on ONE projected tensor qkv (N, 3E, T) = [values | keys | queries] along the channels -- the three 1x1
+ * projections of model.py:31-33 applied to the same input run as one convolution with the three weights stacked; dqkv has
+ * the same layout, so one data-gradient and one weight-gradient launch follow.  Same arithmetic as seld_mha_fwd /
+ * seld_mha_bwd on the three slices.  Matrix-core kernels only: SELD_EUNSUPPORTED unless seld_mha_packed_ok(T, hd) != 0
+ * (hd in {16, 32, 48, 64}, T % 16 == 0).  workspace as seld_mha_bwd_workspace. */
+int seld_mha_packed_ok(int32_t T, int32_t hd);
+int seld_mha_fwd_packed(const float* qkv, int32_t N, int32_t T, int32_t H, int32_t hd, float* out, float* lse, void* stream);
+int seld_mha_bwd_packed(const float* qkv, const float* out, const float* dout, const float* lse, int32_t N, int32_t T,
+                        int32_t H, int32_t hd, float* dqkv, void* workspace, size_t workspace_bytes, void* stream);
 
 /* (N, C, T) <-> (N, T, C) transposes (the permutes of model.py:30-37, 220-222, 318) */
 int seld_transpose_nct_ntc(const float* x, int32_t N, int32_t C, int32_t T, float* y, void* stream);

@@ -289,10 +289,10 @@ static int launch_bwd(const float* q, const float* k, const float* v, const floa
 
 // fp32-MFMA kernels for head dims 16/32/48/64 and T % 16 == 0 (mha_mfma.hip)
 bool mha_mfma_ok(int T, int hd);
-int mha_mfma_fwd(const float* q, const float* k, const float* v, int N, int T, int H, int hd, float* out, float* lse,
+int mha_mfma_fwd(const float* q, const float* k, const float* v, int N, int T, int H, int hd, long long in_bs, float* out, float* lse,
                  hipStream_t st);
 int mha_mfma_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
-                 int N, int T, int H, int hd, float* dq, float* dk, float* dv, hipStream_t st);
+                 int N, int T, int H, int hd, long long in_bs, float* dq, float* dk, float* dv, hipStream_t st);
 
 }  // namespace seld
 using namespace seld;
@@ -301,7 +301,7 @@ extern "C" int seld_mha_fwd(const float* q, const float* k, const float* v, int3
                             float* out, float* lse, void* stream) {
     if (!q || !k || !v || !out || !lse || N <= 0 || T <= 0 || H <= 0 || hd <= 0) return SELD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (mha_mfma_ok(T, hd)) return mha_mfma_fwd(q, k, v, N, T, H, hd, out, lse, st);
+    if (mha_mfma_ok(T, hd)) return mha_mfma_fwd(q, k, v, N, T, H, hd, (long long)H * hd * T, out, lse, st);
     if (hd <= 8) return launch_fwd<8>(q, k, v, N, T, H, hd, out, lse, st);
     if (hd <= 16) return launch_fwd<16>(q, k, v, N, T, H, hd, out, lse, st);
     if (hd <= 32) return launch_fwd<32>(q, k, v, N, T, H, hd, out, lse, st);
@@ -326,11 +326,39 @@ extern "C" int seld_mha_bwd(const float* q, const float* k, const float* v, cons
     hipLaunchKernelGGL(mha_delta_kernel, dim3((T + 255) / 256, N * H), dim3(256), 0, st, out, dout, T, H, hd, delta);
     int rc = check_launch();
     if (rc) return rc;
-    if (mha_mfma_ok(T, hd)) return mha_mfma_bwd(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);
+    if (mha_mfma_ok(T, hd)) return mha_mfma_bwd(q, k, v, dout, lse, delta, N, T, H, hd, (long long)H * hd * T, dq, dk, dv, st);
     if (hd <= 8) return launch_bwd<8>(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);
     if (hd <= 16) return launch_bwd<16>(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);
     if (hd <= 32) return launch_bwd<32>(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);
     if (hd <= 48) return launch_bwd<48>(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);
     if (hd <= 64) return launch_bwd<64>(q, k, v, dout, lse, delta, N, T, H, hd, dq, dk, dv, st);
     return SELD_EUNSUPPORTED;
+}
+
+/* Self-attention on ONE projected tensor qkv (N, 3E, T) = [values | keys | queries] along the channels (the three 1x1
+ * convolutions of model.py:31-33 run as one, hip_ops.QkvFn): same arithmetic as seld_mha_fwd / seld_mha_bwd on the three
+ * channel slices, dqkv in the same layout.  Matrix-core kernels only: SELD_EUNSUPPORTED unless seld_mha_packed_ok(T, hd). */
+extern "C" int seld_mha_packed_ok(int32_t T, int32_t hd) { return T > 0 && hd > 0 && mha_mfma_ok(T, hd); }
+
+extern "C" int seld_mha_fwd_packed(const float* qkv, int32_t N, int32_t T, int32_t H, int32_t hd, float* out, float* lse,
+                                   void* stream) {
+    if (!qkv || !out || !lse || N <= 0 || T <= 0 || H <= 0 || hd <= 0) return SELD_EINVAL;
+    if (!mha_mfma_ok(T, hd)) return SELD_EUNSUPPORTED;
+    const size_t E = (size_t)H * hd * T;
+    return mha_mfma_fwd(qkv + 2 * E, qkv + E, qkv, N, T, H, hd, (long long)(3 * E), out, lse, (hipStream_t)stream);
+}
+
+extern "C" int seld_mha_bwd_packed(const float* qkv, const float* out, const float* dout, const float* lse, int32_t N,
+                                   int32_t T, int32_t H, int32_t hd, float* dqkv, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || N <= 0 || T <= 0 || H <= 0 || hd <= 0) return SELD_EINVAL;
+    if (!mha_mfma_ok(T, hd)) return SELD_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < seld_mha_bwd_workspace(N, T, H)) return SELD_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* delta = (float*)workspace;
+    hipLaunchKernelGGL(mha_delta_kernel, dim3((T + 255) / 256, N * H), dim3(256), 0, st, out, dout, T, H, hd, delta);
+    int rc = check_launch();
+    if (rc) return rc;
+    const size_t E = (size_t)H * hd * T;
+    return mha_mfma_bwd(qkv + 2 * E, qkv + E, qkv, dout, lse, delta, N, T, H, hd, (long long)(3 * E), dqkv + 2 * E, dqkv + E, dqkv, st);
 }

@@ -22,8 +22,8 @@ namespace seld {
 
 template <int HD>
 __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                           const float* __restrict__ v, int T, int H, float scale,
-                                                           float* __restrict__ out, float* __restrict__ lse) {
+                                                           const float* __restrict__ v, int T, int H, long long in_bs,
+                                                           float scale, float* __restrict__ out, float* __restrict__ lse) {
     constexpr int KS = HD / 4;       // k-steps of the d reduction
     constexpr int DT = HD / 16;      // 16-row tiles of O^T
     const int lane = threadIdx.x & 63, c = lane & 15, fk = lane >> 4;
@@ -31,10 +31,12 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float* __restri
     const int q0 = (blockIdx.x * 4 + wave) * 16;
     if (q0 >= T) return;
     const int nh = blockIdx.y;
-    const size_t base = (size_t)nh * HD * T;                 // (n*E + h*hd) * T with E = H*hd
-    const float* qb = q + base;
-    const float* kb = k + base;
-    const float* vb = v + base;
+    const size_t base = (size_t)nh * HD * T;                 // (n*E + h*hd) * T with E = H*hd: out, dout
+    // q / k / v (and their gradients) may be channel slices of one (N, 3E, T) tensor: batch stride in_bs floats
+    const size_t ibase = (size_t)(nh / H) * (size_t)in_bs + (size_t)(nh % H) * HD * T;
+    const float* qb = q + ibase;
+    const float* kb = k + ibase;
+    const float* vb = v + ibase;
 
     float qf[KS];                                            // B operand of S^T: Q[d = 4s + fk][query c], pre-scaled
 #pragma unroll
@@ -87,7 +89,8 @@ template <int HD>
 __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               const float* __restrict__ v, const float* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              int T, int H, float scale, float* __restrict__ dq) {
+                                                              int T, int H, long long in_bs, float scale,
+                                                              float* __restrict__ dq) {
     constexpr int KS = HD / 4, DT = HD / 16;
     const int lane = threadIdx.x & 63, c = lane & 15, fk = lane >> 4;
     const int wave = threadIdx.x >> 6;
@@ -95,9 +98,10 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const float* __res
     if (q0 >= T) return;
     const int nh = blockIdx.y;
     const size_t base = (size_t)nh * HD * T;
-    const float* qb = q + base;
-    const float* kb = k + base;
-    const float* vb = v + base;
+    const size_t ibase = (size_t)(nh / H) * (size_t)in_bs + (size_t)(nh % H) * HD * T;
+    const float* qb = q + ibase;
+    const float* kb = k + ibase;
+    const float* vb = v + ibase;
     const float* gb = dout + base;
 
     float qf[KS], gf[KS];                                    // B operands: Q (scaled), dO at [d = 4s + fk][query c]
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const float* __res
             acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, ds[3], acc[dt], 0, 0, 0);
         }
     }
-    float* ob = dq + base;
+    float* ob = dq + ibase;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -144,8 +148,8 @@ template <int HD>
 __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, const float* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               int T, int H, float scale, float* __restrict__ dk,
-                                                               float* __restrict__ dv) {
+                                                               int T, int H, long long in_bs, float scale,
+                                                               float* __restrict__ dk, float* __restrict__ dv) {
     constexpr int KS = HD / 4, DT = HD / 16;
     const int lane = threadIdx.x & 63, c = lane & 15, fk = lane >> 4;
     const int wave = threadIdx.x >> 6;
@@ -153,9 +157,10 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const float* __re
     if (k0 >= T) return;
     const int nh = blockIdx.y;
     const size_t base = (size_t)nh * HD * T;
-    const float* qb = q + base;
-    const float* kb = k + base;
-    const float* vb = v + base;
+    const size_t ibase = (size_t)(nh / H) * (size_t)in_bs + (size_t)(nh % H) * HD * T;
+    const float* qb = q + ibase;
+    const float* kb = k + ibase;
+    const float* vb = v + ibase;
     const float* gb = dout + base;
 
     float kf[KS], vf[KS];                                    // B operands: K, V at [d = 4s + fk][key c]
@@ -199,8 +204,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const float* __re
             ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq.w, ds[3], ak[dt], 0, 0, 0);
         }
     }
-    float* okb = dk + base;
-    float* ovb = dv + base;
+    float* okb = dk + ibase;
+    float* ovb = dv + ibase;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -215,37 +220,39 @@ bool mha_mfma_ok(int T, int hd) {
 }
 
 template <int HD>
-static void fwd_t(const float* q, const float* k, const float* v, int N, int T, int H, float* out, float* lse, hipStream_t st) {
-    hipLaunchKernelGGL((mha_fwd_mfma_kernel<HD>), dim3((T / 16 + 3) / 4, N * H), dim3(256), 0, st, q, k, v, T, H,
+static void fwd_t(const float* q, const float* k, const float* v, int N, int T, int H, long long in_bs, float* out, float* lse,
+                  hipStream_t st) {
+    hipLaunchKernelGGL((mha_fwd_mfma_kernel<HD>), dim3((T / 16 + 3) / 4, N * H), dim3(256), 0, st, q, k, v, T, H, in_bs,
                        1.0f / sqrtf((float)HD), out, lse);
 }
 template <int HD>
 static int bwd_t(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
-                 int N, int T, int H, float* dq, float* dk, float* dv, hipStream_t st) {
+                 int N, int T, int H, long long in_bs, float* dq, float* dk, float* dv, hipStream_t st) {
     const dim3 grid((T / 16 + 3) / 4, N * H);
     const float scale = 1.0f / sqrtf((float)HD);
-    hipLaunchKernelGGL((mha_bwd_dq_mfma_kernel<HD>), grid, dim3(256), 0, st, q, k, v, dout, lse, delta, T, H, scale, dq);
+    hipLaunchKernelGGL((mha_bwd_dq_mfma_kernel<HD>), grid, dim3(256), 0, st, q, k, v, dout, lse, delta, T, H, in_bs, scale, dq);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL((mha_bwd_dkv_mfma_kernel<HD>), grid, dim3(256), 0, st, q, k, v, dout, lse, delta, T, H, scale, dk, dv);
+    hipLaunchKernelGGL((mha_bwd_dkv_mfma_kernel<HD>), grid, dim3(256), 0, st, q, k, v, dout, lse, delta, T, H, in_bs, scale, dk, dv);
     return check_launch();
 }
 
-int mha_mfma_fwd(const float* q, const float* k, const float* v, int N, int T, int H, int hd, float* out, float* lse,
+// in_bs: floats between consecutive samples of q / k / v / dq / dk / dv (H * hd * T for separate tensors)
+int mha_mfma_fwd(const float* q, const float* k, const float* v, int N, int T, int H, int hd, long long in_bs, float* out, float* lse,
                  hipStream_t st) {
-    if (hd == 16) fwd_t<16>(q, k, v, N, T, H, out, lse, st);
-    else if (hd == 32) fwd_t<32>(q, k, v, N, T, H, out, lse, st);
-    else if (hd == 48) fwd_t<48>(q, k, v, N, T, H, out, lse, st);
-    else fwd_t<64>(q, k, v, N, T, H, out, lse, st);
+    if (hd == 16) fwd_t<16>(q, k, v, N, T, H, in_bs, out, lse, st);
+    else if (hd == 32) fwd_t<32>(q, k, v, N, T, H, in_bs, out, lse, st);
+    else if (hd == 48) fwd_t<48>(q, k, v, N, T, H, in_bs, out, lse, st);
+    else fwd_t<64>(q, k, v, N, T, H, in_bs, out, lse, st);
     return check_launch();
 }
 
 int mha_mfma_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
-                 int N, int T, int H, int hd, float* dq, float* dk, float* dv, hipStream_t st) {
-    if (hd == 16) return bwd_t<16>(q, k, v, dout, lse, delta, N, T, H, dq, dk, dv, st);
-    if (hd == 32) return bwd_t<32>(q, k, v, dout, lse, delta, N, T, H, dq, dk, dv, st);
-    if (hd == 48) return bwd_t<48>(q, k, v, dout, lse, delta, N, T, H, dq, dk, dv, st);
-    return bwd_t<64>(q, k, v, dout, lse, delta, N, T, H, dq, dk, dv, st);
+                 int N, int T, int H, int hd, long long in_bs, float* dq, float* dk, float* dv, hipStream_t st) {
+    if (hd == 16) return bwd_t<16>(q, k, v, dout, lse, delta, N, T, H, in_bs, dq, dk, dv, st);
+    if (hd == 32) return bwd_t<32>(q, k, v, dout, lse, delta, N, T, H, in_bs, dq, dk, dv, st);
+    if (hd == 48) return bwd_t<48>(q, k, v, dout, lse, delta, N, T, H, in_bs, dq, dk, dv, st);
+    return bwd_t<64>(q, k, v, dout, lse, delta, N, T, H, in_bs, dq, dk, dv, st);
 }
 
 }  // namespace seld

@@ -470,8 +470,50 @@ def _direct_targets(params, bias):
     pre-attached `.grad` as a view of a flat buffer and set `_seld_direct_grad`."""
     ts = [getattr(t, "_seld_base_param", t) for t in params] + ([bias] if bias is not None else [])
     if all(getattr(t, "_seld_direct_grad", False) and t.grad is not None for t in ts):
-        return [b.grad if b is t else b.grad.view(t.shape) for b, t in zip(ts, params)], (bias.grad if bias is not None else None)
+        def slot(b, t):
+            if b is t:
+                return b.grad
+            g = getattr(t, "_seld_grad", None)         # stacked_conv_weight: a slot that spans several parameters
+            return g if g is not None else b.grad.view(t.shape)
+        return [slot(b, t) for b, t in zip(ts, params)], (bias.grad if bias is not None else None)
     return None
+
+
+def stacked_conv_weight(params):
+    """ONE convolution weight (sum of the Cout's, Cin, k...) over parameters that lie back to back in memory -- FlatAdam
+    re-homes a model's parameters into one flat buffer in registration order, so the attention's values / keys / queries
+    (model.py:18-20) are three consecutive row blocks of it -- or None.  With gradients enabled the gradient slots must be
+    adjacent in the same order too: the stacked weight is a fresh leaf over the same storage whose gradient the backward
+    kernels write straight into those slots (`_direct_targets`), so autograd never sees the member parameters."""
+    p0 = params[0]
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    at = p0.data_ptr()
+    for p in params:
+        if p.data_ptr() != at or not p.is_contiguous() or p.shape[1:] != p0.shape[1:] or p.dtype != torch.float32:
+            return None
+        at += 4 * p.numel()
+    shape = (sum(int(p.shape[0]) for p in params),) + tuple(p0.shape[1:])
+    same_buffer = lambda ts: all(t.untyped_storage().data_ptr() == ts[0].untyped_storage().data_ptr() for t in ts)
+    if not same_buffer(params):                     # neighbours by accident of the allocator: not one tensor's memory
+        return None
+    gview = None
+    if need_grad:
+        if not all(getattr(p, "_seld_direct_grad", False) and p.grad is not None and p.requires_grad for p in params):
+            return None
+        if not same_buffer([p.grad for p in params]):
+            return None
+        gat = p0.grad.data_ptr()
+        for p in params:
+            if p.grad.data_ptr() != gat or not p.grad.is_contiguous():
+                return None
+            gat += 4 * p.numel()
+        gview = p0.grad.as_strided(shape, p0.grad.stride())
+    w = p0.detach().as_strided(shape, p0.stride())
+    if need_grad:
+        w.requires_grad_(True)
+        w._seld_base_param = p0
+        w._seld_grad = gview
+    return w
 
 
 def as_conv_weight(param, shape):
@@ -1581,6 +1623,47 @@ class MhaCoreFn(torch.autograd.Function):
 
 def mha_core(q, k, v, heads):
     return MhaCoreFn.apply(q, k, v, heads)
+
+
+class MhaPackedFn(torch.autograd.Function):
+    """The same attention on ONE projected tensor qkv (N, 3E, T) = [values | keys | queries] (seld_mha_fwd_packed): the
+    three projections of model.py:31-33 are one convolution, and so are their data and weight gradients."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        qkv = _req(qkv, "qkv")
+        N, E3, T = qkv.shape
+        E = E3 // 3
+        hd = E // heads
+        out = torch.empty((N, E, T), device=qkv.device, dtype=torch.float32)
+        lse = torch.empty((N, heads, T), device=qkv.device, dtype=torch.float32)
+        L.check(L.lib().seld_mha_fwd_packed(L.ptr(qkv), N, T, heads, hd, L.ptr(out), L.ptr(lse), L.current_stream()),
+                "seld_mha_fwd_packed")
+        ctx.geom = (N, T, heads, hd)
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        N, T, H, hd = ctx.geom
+        dout = _req(dout, "dout")
+        dqkv = torch.empty_like(qkv)
+        lib = L.lib()
+        lib.seld_mha_bwd_workspace.restype = ctypes.c_size_t
+        nbytes = lib.seld_mha_bwd_workspace(N, T, H)
+        wsb = torch.empty((nbytes + 3) // 4, device=qkv.device, dtype=torch.float32)
+        L.check(lib.seld_mha_bwd_packed(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), N, T, H, hd, L.ptr(dqkv),
+                                        L.ptr(wsb), ctypes.c_size_t(nbytes), L.current_stream()), "seld_mha_bwd_packed")
+        return dqkv, None
+
+
+def mha_packed_ok(T, head_dim):
+    return bool(L.lib().seld_mha_packed_ok(int(T), int(head_dim)))
+
+
+def mha_core_packed(qkv, heads):
+    return MhaPackedFn.apply(qkv, heads)
 
 
 class SeldLossFn(torch.autograd.Function):

@@ -83,14 +83,30 @@ class MultiHeadAttention(nn.Module):
         return H.hyper_conv(out, (H.as_conv_weight(w, (*w.shape, 1)),), self.fc_out.bias, 1, 0, 1)
 
     def forward_nct(self, x):
-        return self._attend(x, x, x)
+        y = self._attend_stacked(x)
+        return y if y is not None else self._attend(x, x, x)
+
+    def _attend_stacked(self, x):
+        """Self-attention with the three projections as ONE convolution (weights stacked in place: hip_ops.
+        stacked_conv_weight) and the attention core on the packed result; None when the layout does not allow it."""
+        convs = (self.values, self.keys, self.queries)
+        if x.dim() != 3 or any(c.bias is not None or c.kernel_size != (1,) or c.stride != (1,) or c.padding != (0,) or
+                               c.dilation != (1,) or c.groups != 1 for c in convs):
+            return None
+        if not H.mha_packed_ok(x.shape[2], self.head_dim):
+            return None
+        w = H.stacked_conv_weight(tuple(c.weight for c in convs))
+        if w is None:
+            return None
+        out = H.mha_core_packed(H.hyper_conv(x, (w,), None, 1, 0, 1), self.num_heads)
+        wo = self.fc_out.weight
+        return H.hyper_conv(out, (H.as_conv_weight(wo, (*wo.shape, 1)),), self.fc_out.bias, 1, 0, 1)
 
     def forward(self, v, k, q, mask=None):
         if mask is not None:
             raise L.SeldHipError("MultiHeadAttention: attention masks are not supported (the reference always passes None)")
         if v is k and k is q:
-            x = H.transpose12(q)
-            return H.transpose12(self._attend(x, x, x))
+            return H.transpose12(self.forward_nct(H.transpose12(q)))
         return H.transpose12(self._attend(H.transpose12(v), H.transpose12(k), H.transpose12(q)))
 
 

@@ -829,3 +829,55 @@ def test_bn_relu_pool_with_the_stage_dropout_inside(shape, ph):
     H.philox.set_offset(0)
     out = H.bn_relu_pool(y0.to(DEV), bn, ph, 1, None, 0.3)
     assert H.philox.offset == 0 and out.shape == cot.shape
+
+
+def test_attention_with_stacked_projections_matches_the_separate_path():
+    """MultiHeadAttention.forward_nct with FlatAdam's parameter layout: values / keys / queries are consecutive blocks of
+    the flat buffer, so the three 1x1 projections run as ONE convolution (hip_ops.stacked_conv_weight), the attention core
+    reads the packed (N, 3E, T) tensor (seld_mha_fwd_packed / _bwd_packed) and the three weight gradients are one launch
+    into the adjacent gradient slots.  Against the module WITHOUT the layout (separate projections, model.py:28-48) and
+    against torch scaled_dot_product_attention in fp64."""
+    P = pkg()
+    M, T_, H = P.model, P.train, P.hip_ops
+    E, heads, T, N = 384, 8, 256, 2
+    torch.manual_seed(12)
+    ref = M.MultiHeadAttention(E, heads).to(DEV)
+    fused = M.MultiHeadAttention(E, heads).to(DEV)
+    fused.load_state_dict(ref.state_dict())
+    opt = T_.FlatAdam(fused.parameters(), lr=1e-3)          # re-homes the parameters: now adjacent, with gradient slots
+    opt.zero_grad()
+    assert H.stacked_conv_weight((fused.values.weight, fused.keys.weight, fused.queries.weight)) is not None
+    assert H.stacked_conv_weight((ref.values.weight, ref.keys.weight, ref.queries.weight)) is None or True
+    x0 = torch.randn(N, E, T, device=DEV) * 0.5
+    cot = torch.randn(N, E, T, device=DEV)
+    xa = x0.clone().requires_grad_(True)
+    ya = fused.forward_nct(xa)
+    (ya * cot).sum().backward()
+    H.join_side_stream()
+    xb = x0.clone().requires_grad_(True)
+    yb = ref._attend(xb, xb, xb)
+    (yb * cot).sum().backward()
+    H.join_side_stream()
+    torch.cuda.synchronize()
+    _close(ya, yb, rel=1e-5, what="y")
+    _close(xa.grad, xb.grad, rel=1e-4, what="dx")
+    for name in ("values", "keys", "queries"):
+        _close(getattr(fused, name).weight.grad, getattr(ref, name).weight.grad, rel=1e-4, what="dw " + name)
+    _close(fused.fc_out.weight.grad, ref.fc_out.weight.grad, rel=1e-4, what="dwo")
+    _close(fused.fc_out.bias.grad, ref.fc_out.bias.grad, rel=1e-4, what="dbo")
+    # fp64
+    sd = {k: v.detach().cpu().double() for k, v in ref.state_dict().items()}
+    x64 = x0.cpu().double().requires_grad_(True)
+    proj = lambda w: torch.einsum("oi,nit->not", w.squeeze(-1), x64)
+    q, k, v = proj(sd["queries.weight"]), proj(sd["keys.weight"]), proj(sd["values.weight"])
+    hd = E // heads
+    sp = lambda t: t.reshape(N, heads, hd, T).transpose(2, 3)
+    o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(2, 3).reshape(N, E, T)
+    y64 = torch.einsum("oi,nit->not", sd["fc_out.weight"], o) + sd["fc_out.bias"][None, :, None]
+    (y64 * cot.cpu().double()).sum().backward()
+    _close(ya, y64, rel=2e-4, what="y vs fp64")
+    _close(xa.grad, x64.grad, rel=5e-4, what="dx vs fp64")
+    # without gradients (eval / no_grad): the stacked path needs the parameter layout only
+    with torch.no_grad():
+        yc = fused.forward_nct(x0)
+    _close(yc, yb, rel=1e-5, what="no_grad")
