@@ -89,6 +89,14 @@ def pmc_traffic(kernel_label):
         kernels = json.load(open(files[-1]))["kernels"]
     except (OSError, ValueError, KeyError):
         return None, None
+    if kernel_label.startswith("first_stage_fwd"):
+        # the stage forward is several launches (csrc/first_stage.hip): input second moments, their folds, BatchNorm from them,
+        # the finishing pooling convolution -- its traffic is their sum
+        parts = ("fs_gram_kernel", "fs_sum_parts_kernel", "fs_gram_fold_kernel", "fs_bn_from_gram_kernel", "hcq_first_pool_kernel")
+        hits = [v for name, v in kernels.items() if name.startswith(parts)]
+        if not any(name.startswith("hcq_first_pool_kernel") for name in kernels):
+            return None, os.path.relpath(files[-1], ROOT)
+        return round(sum(v["traffic_bytes"] for v in hits)), os.path.relpath(files[-1], ROOT)
     k = kernels.get(kernel_label)
     if k is None:          # the timer's label may carry fewer template arguments than the profiler's symbol
         stem = kernel_label.rstrip(">")
