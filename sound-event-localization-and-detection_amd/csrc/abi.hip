@@ -34,6 +34,7 @@ static void load_env_locked() {
     e.conv_pair = flag("SELD_CONV_PAIR");
     e.conv_no_hcq = flag("SELD_CONV_NO_HCQ");
     e.hcq_wgrad_dq = flag("SELD_HCQ_WGRAD_DQ");
+    e.stft_radix2 = flag("SELD_STFT_RADIX2");
     e.hcq_no_first = flag("SELD_HCQ_NO_FIRST");
     e.hcq_no_pool = flag("SELD_HCQ_NO_POOL");
     e.hcq_wgrad_row = flag("SELD_HCQ_WGRAD_ROW");

@@ -24,6 +24,7 @@ struct SeldEnv {
     bool conv_no_hcq = false;                       // SELD_CONV_NO_HCQ: 16/48-product kernels instead of hcq_conv.hip
     bool hcq_wgrad_row = false;                     // SELD_HCQ_WGRAD_ROW: dual-quaternion weight gradients on the 24-product row kernel
     bool hcq_no_pool = false;                       // SELD_HCQ_NO_POOL: first stage without the pooling convolution kernel
+    bool stft_radix2 = false;                       // SELD_STFT_RADIX2: nperseg 512 on the general radix-2 kernel too
     bool hcq_no_first = false;                      // SELD_HCQ_NO_FIRST: first layers without the row-walking kernel
     bool deterministic = false;                     // SELD_DETERMINISTIC: every reduction in a fixed order (no multi-contributor float atomics)
     bool wgrad_norow = false, wgrad_slow = false, mha_no_mfma = false;

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int rows_pe
 }
 
 // dw = the splits of dM added in order and folded onto the components; threads past the weights write dbias the same way
+template <int KIND>
 __global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, const float* __restrict__ dB, int nz, WPtrsMut dw,
                                    float* __restrict__ dbias) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,7 +285,7 @@ __global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, c
         for (int z = 0; z < nz; ++z) t += dM[z * zs + e];
         return t;
     };
-    const int nw = p.kind == SELD_LIN_REAL ? p.in_f * p.out_f : p.IA * p.OA * p.kind;
+    const int nw = KIND == SELD_LIN_REAL ? p.in_f * p.out_f : p.IA * p.OA * KIND;
     if (idx >= nw) {
         const int o = idx - nw;
         if (dbias && o < p.out_f) {
@@ -295,25 +296,29 @@ __global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, c
         return;
     }
     if (!dw.p[0]) return;
-    if (p.kind == SELD_LIN_REAL) {
+    if constexpr (KIND == SELD_LIN_REAL) {
         const int o = idx / p.in_f, i = idx - o * p.in_f;
         dw.p[0][idx] = at((size_t)i * p.out_f + o);
         return;
+    } else {
+        constexpr int A = KIND;
+        const int per = p.IA * p.OA;
+        const int comp = idx / per;
+        const int rem = idx - comp * per;
+        const int c = rem / p.OA, oo = rem - c * p.OA;
+        float total = 0.f;
+        // the block pattern is a compile-time table once A is: 16 / 64 constant (component, sign) pairs, of which this
+        // thread's component takes 4 / 4-8 (a run-time A cost 64 evaluations of block_comp per element: 15 us per layer)
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int b = 0; b < A; ++b) {
+                float sign = 0.f;
+                const int cc = (KIND == SELD_LIN_QUAT) ? block_comp(4, b, a, &sign) : block_comp(8, a, b, &sign);
+                if (cc == comp) total += sign * at((size_t)(a * p.IA + c) * p.out_f + (size_t)b * p.OA + oo);
+            }
+        dw.p[comp][rem] = total;
     }
-    const int A = p.kind;
-    const int per = p.IA * p.OA;
-    const int comp = idx / per;
-    const int rem = idx - comp * per;
-    const int c = rem / p.OA, oo = rem - c * p.OA;
-    float total = 0.f;
-    for (int a = 0; a < A; ++a)
-        for (int b = 0; b < A; ++b) {
-            float sign;
-            const int cc = (p.kind == SELD_LIN_QUAT) ? block_comp(4, b, a, &sign) : block_comp(8, a, b, &sign);
-            if (cc != comp) continue;
-            total += sign * at((size_t)(a * p.IA + c) * p.out_f + (size_t)b * p.OA + oo);
-        }
-    dw.p[comp][rem] = total;
 }
 
 static int mk_lin(LinP& p, int kind, int in_f, int out_f, const float* const w[8]) {
@@ -398,8 +403,13 @@ extern "C" int seld_hc_linear_bwd(int32_t kind, int32_t rows, int32_t in_feature
         WPtrsMut out{};
         for (int i = 0; i < 8; ++i) out.p[i] = (dw && i < kind) ? dw[i] : nullptr;
         const int total = in_features * out_features / (kind == SELD_LIN_REAL ? 1 : kind) + out_features;   // weights, then bias
-        hipLaunchKernelGGL(linear_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p, (const float*)dM, (const float*)dB, nz, out,
-                           dbias);
+        const dim3 fgrid((total + 255) / 256);
+        if (kind == SELD_LIN_REAL)
+            hipLaunchKernelGGL(linear_fold_kernel<SELD_LIN_REAL>, fgrid, dim3(256), 0, st, p, (const float*)dM, (const float*)dB, nz, out, dbias);
+        else if (kind == SELD_LIN_QUAT)
+            hipLaunchKernelGGL(linear_fold_kernel<SELD_LIN_QUAT>, fgrid, dim3(256), 0, st, p, (const float*)dM, (const float*)dB, nz, out, dbias);
+        else
+            hipLaunchKernelGGL(linear_fold_kernel<SELD_LIN_DUALQ>, fgrid, dim3(256), 0, st, p, (const float*)dM, (const float*)dB, nz, out, dbias);
         rc = check_launch();
     }
     return rc;

@@ -12,6 +12,7 @@
 // |Z| / angle(Z) in an LDS tile [bin][frame] and writes it with the frame index fastest, which is
 // the output's contiguous axis.
 #include "common.h"
+#include "env.h"
 
 namespace seld {
 
@@ -92,6 +93,147 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// N = 512 (the reference's segment length, utility_functions.py:129): one WAVE transforms TWO consecutive frames as the
+// real and imaginary part of one complex signal with three radix-8 Stockham passes -- 8 points per lane in registers,
+// wave-private LDS exchanges (skewed by one float per 8: conflict-free), no workgroup barrier inside the transform --
+// and separates them afterwards (A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i).  The radix-2 kernel
+// above spends 11 workgroup barriers per frame on a complex transform of real input: 248 us for a 60 s x 8 channel clip
+// (7 % of HBM); this one is bound by its sqrt / atan2 and the tile transpose.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Cx { float re, im; };
+__device__ __forceinline__ Cx cadd(Cx a, Cx b) { return Cx{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ Cx csub(Cx a, Cx b) { return Cx{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ Cx cmul(Cx a, Cx b) { return Cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ Cx cmul_mi(Cx a) { return Cx{a.im, -a.re}; }          // a * (-i)
+
+// forward 8-point DFT in place, outputs in natural order
+__device__ __forceinline__ void dft8(Cx (&v)[8]) {
+    constexpr float H = 0.70710678118654752f;
+    Cx a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+    Cx a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    Cx a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+    Cx a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+    a5 = Cx{H * (a5.re + a5.im), H * (a5.im - a5.re)};              // * (1 - i) / sqrt 2
+    a6 = cmul_mi(a6);
+    a7 = Cx{H * (a7.im - a7.re), -H * (a7.re + a7.im)};             // * (-1 - i) / sqrt 2
+    // two 4-point transforms: evens from a0..a3, odds from a4..a7
+    {
+        const Cx c0 = cadd(a0, a2), c2 = csub(a0, a2), c1 = cadd(a1, a3), c3 = cmul_mi(csub(a1, a3));
+        v[0] = cadd(c0, c1); v[4] = csub(c0, c1); v[2] = cadd(c2, c3); v[6] = csub(c2, c3);
+    }
+    {
+        const Cx c0 = cadd(a4, a6), c2 = csub(a4, a6), c1 = cadd(a5, a7), c3 = cmul_mi(csub(a5, a7));
+        v[1] = cadd(c0, c1); v[5] = csub(c0, c1); v[3] = cadd(c2, c3); v[7] = csub(c2, c3);
+    }
+}
+
+constexpr int FT512 = 16;                 // frames per workgroup
+constexpr int SK512 = 512 + 64;           // one skewed 512-float array: element i lives at i + (i >> 3)
+__device__ __forceinline__ int sk(int i) { return i + (i >> 3); }
+
+__global__ __launch_bounds__(256) void stft512_kernel(const float* __restrict__ x, int C, int L, int hop, int frames_out,
+                                                      int output_phase, int bin0, const float* __restrict__ window_g,
+                                                      float* __restrict__ out) {
+    constexpr int N = 512, HALF = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* win = smem;                                   // N
+    float* twr = win + N;                                // N: cos(2 pi k / N)
+    float* twi = twr + N;                                // N: -sin(2 pi k / N)
+    float* scr = twi + N;                                // 4 waves x (re[SK512] | im[SK512])
+    float* mag = scr + 4 * 2 * SK512;                    // (HALF + 1) x (FT512 + 1)
+    float* pha = mag + (HALF + 1) * (FT512 + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.y;
+    const int m0 = blockIdx.x * FT512;
+    const int nbins = HALF + 1 - bin0;
+    const float inv_wsum = 1.0f / (0.54f * (float)N);
+    for (int k = tid; k < N; k += 256) {
+        float sn, cs;
+        sincospif(-2.0f * (float)k / (float)N, &sn, &cs);
+        twr[k] = cs;
+        twi[k] = sn;
+        win[k] = window_g ? window_g[k] : (0.54f - 0.46f * cospif(2.0f * (float)k / (float)N)) * inv_wsum;
+    }
+    __syncthreads();
+    const float* xc = x + (size_t)c * L;
+    float* re = scr + wave * 2 * SK512;
+    float* im = re + SK512;
+    for (int pr = wave; pr < FT512 / 2; pr += 4) {
+        const int m = m0 + 2 * pr;
+        if (m >= frames_out) break;                      // wave-uniform
+        const bool has_b = m + 1 < frames_out;
+        const long long sa = (long long)m * hop - HALF, sb = sa + hop;
+        Cx v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n = lane + 64 * r;
+            const long long ia = sa + n, ib = sb + n;
+            const float w = win[n];
+            v[r].re = (ia >= 0 && ia < L) ? xc[ia] * w : 0.f;
+            v[r].im = (has_b && ib >= 0 && ib < L) ? xc[ib] * w : 0.f;
+        }
+        // pass 1 (sub-transform length 1: no twiddles): out[8 j + r]
+        dft8(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { re[sk(8 * lane + r)] = v[r].re; im[sk(8 * lane + r)] = v[r].im; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // pass 2 (length 8): in[j + 64 r] * W_64^(r k), k = j % 8; out[(j / 8) * 64 + k + 8 r]
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[r].re = re[sk(lane + 64 * r)]; v[r].im = im[sk(lane + 64 * r)]; }
+        {
+            const int k = lane & 7;
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], Cx{twr[r * k * 8], twi[r * k * 8]});
+        }
+        dft8(v);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int j0 = (lane >> 3) * 64 + (lane & 7);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { re[sk(j0 + 8 * r)] = v[r].re; im[sk(j0 + 8 * r)] = v[r].im; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // pass 3 (length 64): in[j + 64 r] * W_512^(r j); out[j + 64 r] = Z in natural order
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[r].re = re[sk(lane + 64 * r)]; v[r].im = im[sk(lane + 64 * r)]; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], Cx{twr[r * lane], twi[r * lane]});
+        dft8(v);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { re[sk(lane + 64 * r)] = v[r].re; im[sk(lane + 64 * r)] = v[r].im; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // the two real transforms, bins bin0 .. N/2, into the [bin][frame] tile
+        for (int b = lane; b < nbins; b += 64) {
+            const int k = b + bin0, km = (N - k) & (N - 1);
+            const float zr = re[sk(k)], zi = im[sk(k)], yr = re[sk(km)], yi = im[sk(km)];
+            const float ar = 0.5f * (zr + yr), ai = 0.5f * (zi - yi);
+            const float br = 0.5f * (zi + yi), bi = -0.5f * (zr - yr);
+            const int f = 2 * pr;
+            mag[b * (FT512 + 1) + f] = sqrtf(ar * ar + ai * ai);
+            mag[b * (FT512 + 1) + f + 1] = sqrtf(br * br + bi * bi);
+            if (output_phase) {
+                pha[b * (FT512 + 1) + f] = atan2f(ai, ar);
+                pha[b * (FT512 + 1) + f + 1] = atan2f(bi, br);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                 // the scratch is rewritten by the wave's next pair
+    }
+    __syncthreads();
+    const int nf = (frames_out - m0) < FT512 ? (frames_out - m0) : FT512;
+    for (int e = tid; e < nbins * FT512; e += 256) {
+        const int b = e / FT512, f = e - b * FT512;
+        if (f < nf) {
+            out[((size_t)c * nbins + b) * frames_out + m0 + f] = mag[b * (FT512 + 1) + f];
+            if (output_phase) out[((size_t)(C + c) * nbins + b) * frames_out + m0 + f] = pha[b * (FT512 + 1) + f];
+        }
+    }
+}
+
 static int frames_total(int L, int N, int noverlap) {
     const int hop = N - noverlap;
     if (hop <= 0) return -1;
@@ -123,6 +265,12 @@ extern "C" int seld_stft_magphase_ex(const float* x, int32_t C, int32_t L, int32
     const int frames = frames_total(L, nperseg, noverlap) - (cut_last_timeframe ? 1 : 0);
     if (frames <= 0) return SELD_EINVAL;
     const int half = nperseg / 2;
+    if (nperseg == 512 && !env().stft_radix2) {
+        const size_t smem512 = sizeof(float) * ((size_t)3 * 512 + (size_t)4 * 2 * SK512 + (size_t)2 * 257 * (FT512 + 1));
+        hipLaunchKernelGGL(stft512_kernel, dim3((frames + FT512 - 1) / FT512, C), dim3(256), smem512, (hipStream_t)stream, x, C, L,
+                           nperseg - noverlap, frames, output_phase, cut_dc ? 1 : 0, window, out);
+        return check_launch();
+    }
     const size_t smem = sizeof(float) * ((size_t)2 * nperseg * 2 + (size_t)half * 2 + nperseg + (size_t)2 * (half + 1) * (FT + 1));
     dim3 grid((frames + FT - 1) / FT, C);
     hipLaunchKernelGGL(stft_kernel, grid, dim3(256), smem, (hipStream_t)stream, x, C, L, nperseg, logN,
