@@ -100,7 +100,9 @@ __device__ __forceinline__ void xforms(const float b[4], float g[8]) {
 // in both ranges (NR = 1: quaternion, one range), XI staging items per thread.
 // The channel tile p.mix_ytile (dual quaternion with 24 block channels, split layout) runs the same program with other
 // descriptors: its range-0-only tile is padding, its both-range tile is descriptor slot 2 (8 channels of each half).
-template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI>
+// MX: the launch has mixed-tile workgroups, whose copy of the K loop leaves the padding slots out (a second copy of the
+// loop costs registers -- 186 instead of 160 for the TCN 1x3 shape -- so launches without such workgroups keep MX = false).
+template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI, bool MX = false>
 __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     constexpr int TAPS = KH * KW;
     constexpr int NT = NT1 + NT2;
@@ -228,12 +230,13 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     constexpr int NPC = NR * NPAIR;                          // fragment pairs per chunk
 
     bool dbg_started = false;
-    auto load_b1 = [&](const float* blk, int j, int m, auto ntrc) __attribute__((always_inline)) {
-        constexpr int NTR = decltype(ntrc)::value;
+    // T0: first tile that is loaded (a mixed-tile workgroup's range-0-only slots are padding: neither loaded nor multiplied)
+    auto load_b1 = [&](const float* blk, int j, int m, auto ntrc, auto t0c) __attribute__((always_inline)) {
+        constexpr int NTR = decltype(ntrc)::value, T0 = decltype(t0c)::value;
         if ((HCQ_DBG & 1) && dbg_started) return;
         const float* q = blk + ((long long)(j * 8 + m) * 64 + lane) * (2 * NTR);
 #pragma unroll
-        for (int t = 0; t < NTR; ++t) bfr[m][t] = *reinterpret_cast<const float2*>(q + 2 * t);
+        for (int t = T0; t < NTR; ++t) bfr[m][t] = *reinterpret_cast<const float2*>(q + 2 * t);
     };
     auto read_raw = [&](const float* xs, int g) __attribute__((always_inline)) {
         if ((HCQ_DBG & 2) && dbg_started) return;
@@ -246,11 +249,17 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
     using INT2 = std::integral_constant<int, NT2>;
 
     // ---- K loop ------------------------------------------------------------------------------------------------
+    // MIX: the workgroup of the mixed 8 + 8 tile (descriptor slot 2 in accumulator slot NT1).  Its range-0-only slots are
+    // padding; round 2 ran the same program on zero weights for them (a third of such a workgroup's MFMAs), now they are
+    // compiled out of its copy of the loop.
     const int nchunks = p.nch * p.nsrc;
+    auto kloop = [&](auto mixc) __attribute__((always_inline)) {
+    constexpr bool MIX = decltype(mixc)::value;
+    using IT0 = std::integral_constant<int, MIX ? NT1 : 0>;
     load_x();
     store_x(0);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) load_b1(wbase, 0, m, INT{});
+    for (int m = 0; m < 8; ++m) load_b1(wbase, 0, m, INT{}, IT0{});
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
             for (int m = 0; m < 8; ++m) {
                 if (r == 0) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                    for (int t = MIX ? NT1 : 0; t < NT; ++t)
                         acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(gm[gst][m], (g & 1) ? bfr[m][t].y : bfr[m][t].x,
                                                                           acc[t][m], 0, 0, 0);
                 } else {
@@ -294,10 +303,10 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
                     const int pn = pc + 1;
                     if (pn < NPC) {
                         const int rn = pn / NPAIR, jn = pn - rn * NPAIR;
-                        if (rn == 0) load_b1(wc, jn, m, INT{});
-                        else load_b1(wc + p.range_stride[0], jn, m, INT2{});
+                        if (rn == 0) load_b1(wc, jn, m, INT{}, IT0{});
+                        else load_b1(wc + p.range_stride[0], jn, m, INT2{}, I0{});
                     } else if (more) {
-                        load_b1(wn, 0, m, INT{});
+                        load_b1(wn, 0, m, INT{}, IT0{});
                     }
                 }
             }
@@ -306,6 +315,14 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
         }
         if (ch + 1 < nchunks && !(HCQ_DBG & 4)) store_x(buf ^ 1);
         if (!(HCQ_DBG & 8)) __syncthreads();
+    }
+    };
+    if constexpr (MX) {
+        static_assert(NR == 2 && NT1 == 1 && NT2 == 1, "the only layout with mixed-tile workgroups");
+        if (mix_wg) kloop(std::true_type{});
+        else kloop(std::false_type{});
+    } else {
+        kloop(std::false_type{});
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
@@ -1205,9 +1222,9 @@ static int hcq_pick(const HcqPlan& pl, HcqKern* k) {
     return 1;
 }
 
-template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI>
+template <int KH, int KW, int IBC, int NT1, int NT2, int NR, int XI, bool MX = false>
 static int hcq_launch_one(const HcqPlan& pl, hipStream_t st) {
-    auto kern = hcq_conv_kernel<KH, KW, IBC, NT1, NT2, NR, XI>;
+    auto kern = hcq_conv_kernel<KH, KW, IBC, NT1, NT2, NR, XI, MX>;
     if (pl.smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem) != hipSuccess)
         return SELD_ELAUNCH;
@@ -1220,6 +1237,7 @@ static int hcq_launch_cfg(const HcqPlan& pl, const HcqKern& k, hipStream_t st) {
     if (k.NR == 2) {
         if (k.XI != XI8) return SELD_EUNSUPPORTED;
         if (k.NT2 == 2) return hcq_launch_one<KH, KW, IBC, 1, 2, 2, XI8>(pl, st);
+        if (pl.mix) return hcq_launch_one<KH, KW, IBC, 1, 1, 2, XI8, true>(pl, st);
         return hcq_launch_one<KH, KW, IBC, 1, 1, 2, XI8>(pl, st);
     }
     if (k.XI != XI4) return SELD_EUNSUPPORTED;
@@ -1299,7 +1317,8 @@ extern "C" int seld_hcq_kernel_label(const seld_conv_desc* d, int32_t mode, int3
     else if (pl.first_rows && hcq_first_takes(pl))   // (label of the plain / statistics epilogue: what the first layer runs)
         snprintf(buf, buflen, "hcq_first_kernel<%d, %d, %d, %d, %d>", k.IBC, k.NT1, k.NT2, k.NR, pl.first_rows);
     else
-        snprintf(buf, buflen, "hcq_conv_kernel<%d, %d, %d, %d, %d, %d, %d>", k.KH, k.KW, k.IBC, k.NT1, k.NT2, k.NR, k.XI);
+        snprintf(buf, buflen, "hcq_conv_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", k.KH, k.KW, k.IBC, k.NT1, k.NT2, k.NR, k.XI,
+                 (pl.mix && k.NR == 2 && k.NT2 == 1) ? "true" : "false");
     return SELD_OK;
 }
 
