@@ -847,7 +847,7 @@ def test_attention_with_stacked_projections_matches_the_separate_path():
     opt = T_.FlatAdam(fused.parameters(), lr=1e-3)          # re-homes the parameters: now adjacent, with gradient slots
     opt.zero_grad()
     assert H.stacked_conv_weight((fused.values.weight, fused.keys.weight, fused.queries.weight)) is not None
-    assert H.stacked_conv_weight((ref.values.weight, ref.keys.weight, ref.queries.weight)) is None or True
+    assert H.stacked_conv_weight((ref.values.weight, ref.keys.weight, ref.queries.weight)) is None       # separate allocations
     x0 = torch.randn(N, E, T, device=DEV) * 0.5
     cot = torch.randn(N, E, T, device=DEV)
     xa = x0.clone().requires_grad_(True)
