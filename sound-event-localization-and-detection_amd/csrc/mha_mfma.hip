@@ -46,13 +46,21 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float* __restri
     for (int dt = 0; dt < DT; ++dt) o[dt] = (floatx4){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;                            // l: this lane's share of the row sum (its 4 keys per tile)
 
-    for (int k0 = 0; k0 < T; k0 += 16) {
+    // A key tile's operands are requested TOGETHER and one tile ahead of their use (two register stages): the first
+    // version asked for each K value right before its MFMA and waited for it there -- 15 exposed cache latencies per tile,
+    // 77 us for config 3's 256 (sample, head) pairs.
+    float ka[2][KS];                                         // A of S^T: K[d = 4s + fk][key k0 + c]
+    float4 va[2][DT];                                        // A of O^T: V[d = 16dt + c][key k0 + 4fk .. +3]
+    auto load_tile = [&](int k0, float (&kr)[KS], float4 (&vr)[DT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kr[s] = kb[(size_t)(4 * s + fk) * T + k0 + c];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vr[dt] = *reinterpret_cast<const float4*>(vb + (size_t)(dt * 16 + c) * T + k0 + 4 * fk);
+    };
+    auto tile = [&](const float (&kr)[KS], const float4 (&vr)[DT]) __attribute__((always_inline)) {
         floatx4 st = {0.f, 0.f, 0.f, 0.f};                   // S^T[key k0 + 4fk + r][query c]
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float a = kb[(size_t)(4 * s + fk) * T + k0 + c];       // A[row = key c][k = d]
-            st = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[s], st, 0, 0, 0);
-        }
+        for (int s = 0; s < KS; ++s) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s], qf[s], st, 0, 0, 0);
         float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -66,13 +74,20 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float* __restri
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             o[dt] *= alpha;
-            // A[row = d][k]: step r takes key k0 + 4fk + r -> one 16-byte load of V[d][k0 + 4fk .. +3]
-            const float4 vv = *reinterpret_cast<const float4*>(vb + (size_t)(dt * 16 + c) * T + k0 + 4 * fk);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, p[0], o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, p[1], o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, p[2], o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, p[3], o[dt], 0, 0, 0);
+            // A[row = d][k]: step r takes key k0 + 4fk + r -> the 4 consecutive keys of one 16-byte load
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[dt].x, p[0], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[dt].y, p[1], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[dt].z, p[2], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[dt].w, p[3], o[dt], 0, 0, 0);
         }
+    };
+    load_tile(0, ka[0], va[0]);
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        if (k0 + 16 < T) load_tile(k0 + 16, ka[1], va[1]);
+        tile(ka[0], va[0]);
+        if (k0 + 16 >= T) break;
+        if (k0 + 32 < T) load_tile(k0 + 32, ka[0], va[0]);
+        tile(ka[1], va[1]);
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -116,26 +131,43 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const float* __res
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < T; k0 += 16) {
+    // operands of a key tile requested together, one tile ahead (see the forward kernel)
+    float ka[2][KS], va[2][KS];                              // A of S^T / dP^T: K, V at [d = 4s + fk][key k0 + c]
+    float4 kk[2][DT];                                        // A of dQ^T: K[d = 16dt + c][key k0 + 4fk .. +3]
+    auto load_tile = [&](int k0, float (&kr)[KS], float (&vr)[KS], float4 (&k4)[DT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kr[s] = kb[(size_t)(4 * s + fk) * T + k0 + c];
+            vr[s] = vb[(size_t)(4 * s + fk) * T + k0 + c];
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) k4[dt] = *reinterpret_cast<const float4*>(kb + (size_t)(dt * 16 + c) * T + k0 + 4 * fk);
+    };
+    auto tile = [&](const float (&kr)[KS], const float (&vr)[KS], const float4 (&k4)[DT]) __attribute__((always_inline)) {
         floatx4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};     // S^T, dP^T [key k0 + 4fk + r][query c]
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const float ak = kb[(size_t)(4 * s + fk) * T + k0 + c];
-            const float av = vb[(size_t)(4 * s + fk) * T + k0 + c];
-            st = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qf[s], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(av, gf[s], dp, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s], qf[s], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s], gf[s], dp, 0, 0, 0);
         }
         float ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ds[r] = __expf(st[r] - my_lse) * (dp[r] - my_delta) * scale;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const float4 kk = *reinterpret_cast<const float4*>(kb + (size_t)(dt * 16 + c) * T + k0 + 4 * fk);
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, ds[0], acc[dt], 0, 0, 0);
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, ds[1], acc[dt], 0, 0, 0);
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, ds[2], acc[dt], 0, 0, 0);
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, ds[3], acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[dt].x, ds[0], acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[dt].y, ds[1], acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[dt].z, ds[2], acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[dt].w, ds[3], acc[dt], 0, 0, 0);
         }
+    };
+    load_tile(0, ka[0], va[0], kk[0]);
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        if (k0 + 16 < T) load_tile(k0 + 16, ka[1], va[1], kk[1]);
+        tile(ka[0], va[0], kk[0]);
+        if (k0 + 16 >= T) break;
+        if (k0 + 32 < T) load_tile(k0 + 32, ka[0], va[0], kk[0]);
+        tile(ka[1], va[1], kk[1]);
     }
     float* ob = dq + ibase;
 #pragma unroll
@@ -175,34 +207,58 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const float* __re
         ak[dt] = (floatx4){0.f, 0.f, 0.f, 0.f};
         av[dt] = (floatx4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int q0 = 0; q0 < T; q0 += 16) {
+    // operands of the first two products (S, dP) of a query tile are requested together one tile ahead; those of the last
+    // two (dV, dK) at the top of their own tile, 24 MFMAs before their use -- two stages of everything is 260 registers
+    struct QTile {
+        float aq[KS], ag[KS];                                // A of S / dP: Q, dO at [d = 4s + fk][query q0 + c]
+        float4 ls, dl;                                       // lse, delta of queries q0 + 4fk .. +3
+    };
+    QTile qt[2];
+    auto load_tile = [&](int q0, QTile& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            t.aq[s] = qb[(size_t)(4 * s + fk) * T + q0 + c];
+            t.ag[s] = gb[(size_t)(4 * s + fk) * T + q0 + c];
+        }
+        t.ls = *reinterpret_cast<const float4*>(lse + (size_t)nh * T + q0 + 4 * fk);
+        t.dl = *reinterpret_cast<const float4*>(delta + (size_t)nh * T + q0 + 4 * fk);
+    };
+    auto tile = [&](int q0, const QTile& t) __attribute__((always_inline)) {
+        float4 gg[DT], qq[DT];                               // A of dV^T / dK^T: dO, Q at [d = 16dt + c][query q0 + 4fk .. +3]
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            gg[dt] = *reinterpret_cast<const float4*>(gb + (size_t)(dt * 16 + c) * T + q0 + 4 * fk);
+            qq[dt] = *reinterpret_cast<const float4*>(qb + (size_t)(dt * 16 + c) * T + q0 + 4 * fk);
+        }
         floatx4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};     // S, dP [query q0 + 4fk + r][key c]
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const float aq = qb[(size_t)(4 * s + fk) * T + q0 + c] * scale;  // A[row = query c][k = d]
-            const float ag = gb[(size_t)(4 * s + fk) * T + q0 + c];
-            st = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, kf[s], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, vf[s], dp, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(t.aq[s] * scale, kf[s], st, 0, 0, 0);   // A[row = query c][k = d]
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(t.ag[s], vf[s], dp, 0, 0, 0);
         }
-        const float4 ls = *reinterpret_cast<const float4*>(lse + (size_t)nh * T + q0 + 4 * fk);    // rows = queries
-        const float4 dl = *reinterpret_cast<const float4*>(delta + (size_t)nh * T + q0 + 4 * fk);
         float p[4], ds[4];
-        p[0] = __expf(st[0] - ls.x); p[1] = __expf(st[1] - ls.y); p[2] = __expf(st[2] - ls.z); p[3] = __expf(st[3] - ls.w);
-        ds[0] = p[0] * (dp[0] - dl.x) * scale; ds[1] = p[1] * (dp[1] - dl.y) * scale;
-        ds[2] = p[2] * (dp[2] - dl.z) * scale; ds[3] = p[3] * (dp[3] - dl.w) * scale;
+        p[0] = __expf(st[0] - t.ls.x); p[1] = __expf(st[1] - t.ls.y); p[2] = __expf(st[2] - t.ls.z); p[3] = __expf(st[3] - t.ls.w);
+        ds[0] = p[0] * (dp[0] - t.dl.x) * scale; ds[1] = p[1] * (dp[1] - t.dl.y) * scale;
+        ds[2] = p[2] * (dp[2] - t.dl.z) * scale; ds[3] = p[3] * (dp[3] - t.dl.w) * scale;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const float4 gg = *reinterpret_cast<const float4*>(gb + (size_t)(dt * 16 + c) * T + q0 + 4 * fk);
-            const float4 qq = *reinterpret_cast<const float4*>(qb + (size_t)(dt * 16 + c) * T + q0 + 4 * fk);
-            av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gg.x, p[0], av[dt], 0, 0, 0);
-            av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gg.y, p[1], av[dt], 0, 0, 0);
-            av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gg.z, p[2], av[dt], 0, 0, 0);
-            av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gg.w, p[3], av[dt], 0, 0, 0);
-            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq.x, ds[0], ak[dt], 0, 0, 0);
-            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq.y, ds[1], ak[dt], 0, 0, 0);
-            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq.z, ds[2], ak[dt], 0, 0, 0);
-            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq.w, ds[3], ak[dt], 0, 0, 0);
+            av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gg[dt].x, p[0], av[dt], 0, 0, 0);
+            av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gg[dt].y, p[1], av[dt], 0, 0, 0);
+            av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gg[dt].z, p[2], av[dt], 0, 0, 0);
+            av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gg[dt].w, p[3], av[dt], 0, 0, 0);
+            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[dt].x, ds[0], ak[dt], 0, 0, 0);
+            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[dt].y, ds[1], ak[dt], 0, 0, 0);
+            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[dt].z, ds[2], ak[dt], 0, 0, 0);
+            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[dt].w, ds[3], ak[dt], 0, 0, 0);
         }
+    };
+    load_tile(0, qt[0]);
+    for (int q0 = 0; q0 < T; q0 += 32) {
+        if (q0 + 16 < T) load_tile(q0 + 16, qt[1]);
+        tile(q0, qt[0]);
+        if (q0 + 16 >= T) break;
+        if (q0 + 32 < T) load_tile(q0 + 32, qt[0]);
+        tile(q0 + 16, qt[1]);
     }
     float* okb = dk + ibase;
     float* ovb = dv + ibase;
