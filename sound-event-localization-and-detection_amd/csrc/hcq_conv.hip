@@ -465,20 +465,32 @@ __global__ __launch_bounds__(256, 2) void hcq_first_kernel(const HcqP p) {
         const int items = A * IBC * XR * qw;
         const unsigned img_base = (unsigned)n_img * (unsigned)p.Csrc * S;
         constexpr float inv_qw = 1.0f / (float)qw;
-        for (int f = tid; f < items; f += 256) {
-            const int row = small_div_h(f, inv_qw);               // (comp * IBC + ibl) * XR + xr
-            const int quad = f - row * qw;
-            const int ci = row / XR;
-            const int xr = row - ci * XR;
-            const int comp = ci / IBC;
-            const int ibl = ci - comp * IBC;
-            const int hh = h0 - (KH - 1) / 2 + xr;
-            const int ww = w0 - DPAD + 4 * quad;
-            const bool ok = (unsigned)hh < (unsigned)p.Himg && (unsigned)ww < (unsigned)p.W;
-            const unsigned e = img_base + ((unsigned)(comp * p.IB + ibl) * (unsigned)p.Himg + (unsigned)hh) * (unsigned)p.W + (unsigned)ww;
-            const uintx4h v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? e * 4u : OOB, 0, 0);
-            *reinterpret_cast<float4*>(lds + (row * qw + quad) * 4) =
-                make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        // four requests in flight per thread, then their four LDS stores (one load -> wait -> store per iteration exposed a
+        // first-touch memory latency six to twelve times at the head of every workgroup)
+        for (int f0 = tid; f0 < items; f0 += 4 * 256) {
+            uintx4h v[4];
+            int dst_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + 256 * u;
+                const int row = small_div_h(f, inv_qw);               // (comp * IBC + ibl) * XR + xr
+                const int quad = f - row * qw;
+                const int ci = row / XR;
+                const int xr = row - ci * XR;
+                const int comp = ci / IBC;
+                const int ibl = ci - comp * IBC;
+                const int hh = h0 - (KH - 1) / 2 + xr;
+                const int ww = w0 - DPAD + 4 * quad;
+                const bool ok = f < items && (unsigned)hh < (unsigned)p.Himg && (unsigned)ww < (unsigned)p.W;
+                const unsigned e = img_base + ((unsigned)(comp * p.IB + ibl) * (unsigned)p.Himg + (unsigned)hh) * (unsigned)p.W + (unsigned)ww;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? e * 4u : OOB, 0, 0);
+                dst_[u] = f < items ? (row * qw + quad) * 4 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst_[u] >= 0)
+                    *reinterpret_cast<float4*>(lds + dst_[u]) =
+                        make_float4(__uint_as_float(v[u][0]), __uint_as_float(v[u][1]), __uint_as_float(v[u][2]), __uint_as_float(v[u][3]));
         }
     }
 
@@ -710,20 +722,32 @@ __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, co
         const int items = A * IBC * XR * qw;
         const unsigned img_base = (unsigned)n_img * (unsigned)p.Csrc * S;
         constexpr float inv_qw = 1.0f / (float)qw;
-        for (int f = tid; f < items; f += 256) {
-            const int row = small_div_h(f, inv_qw);
-            const int quad = f - row * qw;
-            const int ci = row / XR;
-            const int xr = row - ci * XR;
-            const int comp = ci / IBC;
-            const int ibl = ci - comp * IBC;
-            const int hh = h0 - (KH - 1) / 2 + xr;
-            const int ww = w0 - DPAD + 4 * quad;
-            const bool ok = (unsigned)hh < (unsigned)p.Himg && (unsigned)ww < (unsigned)p.W;
-            const unsigned e = img_base + ((unsigned)(comp * p.IB + ibl) * (unsigned)p.Himg + (unsigned)hh) * (unsigned)p.W + (unsigned)ww;
-            const uintx4h v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? e * 4u : OOB, 0, 0);
-            *reinterpret_cast<float4*>(lds + (row * qw + quad) * 4) =
-                make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        // four requests in flight per thread, then their four LDS stores (one load -> wait -> store per iteration exposed a
+        // first-touch memory latency six to twelve times at the head of every workgroup)
+        for (int f0 = tid; f0 < items; f0 += 4 * 256) {
+            uintx4h v[4];
+            int dst_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + 256 * u;
+                const int row = small_div_h(f, inv_qw);               // (comp * IBC + ibl) * XR + xr
+                const int quad = f - row * qw;
+                const int ci = row / XR;
+                const int xr = row - ci * XR;
+                const int comp = ci / IBC;
+                const int ibl = ci - comp * IBC;
+                const int hh = h0 - (KH - 1) / 2 + xr;
+                const int ww = w0 - DPAD + 4 * quad;
+                const bool ok = f < items && (unsigned)hh < (unsigned)p.Himg && (unsigned)ww < (unsigned)p.W;
+                const unsigned e = img_base + ((unsigned)(comp * p.IB + ibl) * (unsigned)p.Himg + (unsigned)hh) * (unsigned)p.W + (unsigned)ww;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? e * 4u : OOB, 0, 0);
+                dst_[u] = f < items ? (row * qw + quad) * 4 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst_[u] >= 0)
+                    *reinterpret_cast<float4*>(lds + dst_[u]) =
+                        make_float4(__uint_as_float(v[u][0]), __uint_as_float(v[u][1]), __uint_as_float(v[u][2]), __uint_as_float(v[u][3]));
         }
     }
     int aoff[NG];
@@ -771,12 +795,22 @@ __global__ __launch_bounds__(256, 3) void hcq_first_pool_kernel(const HcqP p, co
         const int chb = ob0 >= 0 ? p.tile_half[T][grp] * 4 * p.OB + ob0 + (fr & 7) : -1;
         // fragments of tile T only (range 0 blocks hold NT tiles per (pair, form, lane), range 1 blocks NT2): into LDS
         __syncthreads();                                  // everybody is done with the previous tile's fragments
-        for (int e = tid; e < NPCT * 8 * 64; e += 256) {
-            const int ln = e & 63, jm = e >> 6;           // jm = pair * 8 + form over both ranges
-            const int rr = jm / (NPAIR * 8), jm0 = jm - rr * (NPAIR * 8);
-            const float* blk = rr == 0 ? wbase : wbase + p.range_stride[0];
-            const int ntr = rr == 0 ? NT : NT2, tt = rr == 0 ? T : T - NT1;
-            wl[e] = *reinterpret_cast<const float2*>(blk + ((long long)jm0 * 64 + ln) * (2 * ntr) + 2 * tt);
+        {
+            // all of a thread's loads first, then its stores: as one load -> wait -> store per iteration the fill exposed
+            // 4 / 8 / 8 cache latencies per tile, a fifth of the workgroup's time
+            constexpr int NIT = NPCT * 8 * 64 / 256;
+            float2 tmp[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + 256 * it;
+                const int ln = e & 63, jm = e >> 6;       // jm = pair * 8 + form over both ranges
+                const int rr = jm / (NPAIR * 8), jm0 = jm - rr * (NPAIR * 8);
+                const float* blk = rr == 0 ? wbase : wbase + p.range_stride[0];
+                const int ntr = rr == 0 ? NT : NT2, tt = rr == 0 ? T : T - NT1;
+                tmp[it] = *reinterpret_cast<const float2*>(blk + ((long long)jm0 * 64 + ln) * (2 * ntr) + 2 * tt);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) wl[tid + 256 * it] = tmp[it];
         }
         __syncthreads();
         auto load_b1 = [&](int pc, int m) __attribute__((always_inline)) { bfr[m] = wl[(pc * 8 + m) * 64 + lane]; };
