@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const float* __re
             gg[dt] = *reinterpret_cast<const float4*>(gb + (size_t)(dt * 16 + c) * T + q0 + 4 * fk);
             qq[dt] = *reinterpret_cast<const float4*>(qb + (size_t)(dt * 16 + c) * T + q0 + 4 * fk);
         }
+        __builtin_amdgcn_sched_barrier(0);       // (left alone the compiler sinks each of these loads to just before its MFMAs)
         floatx4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};     // S, dP [query q0 + 4fk + r][key c]
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
