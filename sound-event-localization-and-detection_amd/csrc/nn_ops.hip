@@ -489,20 +489,28 @@ __global__ __launch_bounds__(CH_THREADS) void bn_act_bwd_channel_kernel(
     const float mu = mean[c], is = invstd[c], a = gamma[c] * is;
     float4 dz[PER], xh[PER];
     float v[2] = {0.f, 0.f};      // dgamma, dbeta
+    // all loads first, from clamped addresses (see gate_bwd_channel_kernel)
+    float4 ds_[PER], xs_[PER], ys_[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int g = min((int)threadIdx.x + k * CH_THREADS, G - 1);
+        const int n = g / S4, s4 = g - n * S4;
+        const size_t o = ((size_t)n * C + c) * S + (size_t)s4 * 4;
+        ds_[k] = ld4(dy + o); xs_[k] = ld4(x + o); ys_[k] = ld4(y + o);
+        if (dy2) {                           // y had two consumers: their gradients are summed here, not by a separate kernel
+            const float4 e = ld4(dy2 + o);
+            ds_[k].x += e.x; ds_[k].y += e.y; ds_[k].z += e.z; ds_[k].w += e.w;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int g = (int)threadIdx.x + k * CH_THREADS;
         dz[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         xh[k] = dz[k];
         if (g < G) {
-            const int n = g / S4, s4 = g - n * S4;
-            const size_t o = ((size_t)n * C + c) * S + (size_t)s4 * 4;
-            float4 d = ld4(dy + o);
-            const float4 xx = ld4(x + o), yy = ld4(y + o);
-            if (dy2) {                       // y had two consumers: their gradients are summed here, not by a separate kernel
-                const float4 e = ld4(dy2 + o);
-                d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
-            }
+            const float4 d = ds_[k];
+            const float4 xx = xs_[k], yy = ys_[k];
             dz[k] = make_float4(d.x * act_grad_from_y(yy.x, act), d.y * act_grad_from_y(yy.y, act),
                                 d.z * act_grad_from_y(yy.z, act), d.w * act_grad_from_y(yy.w, act));
             xh[k] = make_float4((xx.x - mu) * is, (xx.y - mu) * is, (xx.z - mu) * is, (xx.w - mu) * is);
@@ -541,16 +549,28 @@ __global__ __launch_bounds__(CH_THREADS) void gate_bwd_channel_kernel(
     const float mug = bn.mean_g[c], isg = bn.invstd_g[c], ag = bn.gamma_g[c] * isg, bg = bn.beta_g[c] - mug * ag;
     float dzf[PER][4], dzg[PER][4], fh[PER][4], gh[PER][4];
     float v[4] = {0.f, 0.f, 0.f, 0.f};      // dgamma_f, dbeta_f, dgamma_g, dbeta_g
+    // every operand of the channel is requested before the first one is used (unconditional loads from clamped addresses:
+    // with the loads inside `if (g < G)` the compiler kept each group's load -> wait -> tanh / exp sequence in order, eight
+    // exposed memory latencies per workgroup)
+    float4 d4s[PER], f4s[PER], g4s[PER];
+    float mks[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int g = min((int)threadIdx.x + k * CH_THREADS, G - 1);
+        const int n = g / S4, s4 = g - n * S4;
+        const size_t o = ((size_t)n * C + c) * S + (size_t)s4 * 4;
+        d4s[k] = ld4(dy + o); f4s[k] = ld4(yf + o); g4s[k] = ld4(yg + o);
+        mks[k] = mask ? mask[n * C + c] : 1.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int g = (int)threadIdx.x + k * CH_THREADS;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dzf[k][e] = dzg[k][e] = fh[k][e] = gh[k][e] = 0.f;
         if (g < G) {
-            const int n = g / S4, s4 = g - n * S4;
-            const size_t o = ((size_t)n * C + c) * S + (size_t)s4 * 4;
-            const float4 d4 = ld4(dy + o), f4 = ld4(yf + o), g4 = ld4(yg + o);
-            const float mk = mask ? mask[n * C + c] : 1.0f;
+            const float4 d4 = d4s[k], f4 = f4s[k], g4 = g4s[k];
+            const float mk = mks[k];
             const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, ff[4] = {f4.x, f4.y, f4.z, f4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
