@@ -46,6 +46,9 @@
 #ifndef HCQ_DBG
 #define HCQ_DBG 0
 #endif
+#ifndef HCQ_PIN
+#define HCQ_PIN 1
+#endif
 
 namespace seld {
 
@@ -308,6 +311,10 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
                     } else if (more) {
                         load_b1(wn, 0, m, INT{}, IT0{});
                     }
+                    // keep the request HERE: between two scheduling barriers the compiler moves loads towards their use
+                    // (register pressure), i.e. to the end of this k-group -- a few MFMAs ahead of the wait instead of
+                    // seven forms
+                    if (HCQ_PIN && NT >= 3) __builtin_amdgcn_sched_barrier(0);     // (two-tile shapes: 16 more registers, a wave less)
                 }
             }
             if (!last && !(HCQ_DBG & 2)) xforms(raw, gm[gst ^ 1]);
