@@ -37,24 +37,35 @@ typedef unsigned int uintx4f __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int fs_tri(int t, int u) { return t * 5 - t * (t - 1) / 2 + (u - t); }      // t <= u < 5
 
-// x tile of one block (8 window rows x 64 columns of image n): [channel][10 rows][72 columns], zero outside the image
-__device__ __forceinline__ void fs_stage_x(const float* x, float* lds, int n, int h0, int w0, int H, int W, int tid) {
+// x tile of one block (8 window rows x 64 columns of image n): [channel][10 rows][72 columns], zero outside the image.
+// A thread's FS_XI 16-byte items are requested together (fs_load_x) and written to LDS later (fs_store_x): one load ->
+// wait -> store per loop iteration exposed six memory latencies per block.
+constexpr int FS_XI = (8 * FS_XR * (FS_WEXT / 4) + 255) / 256;
+__device__ __forceinline__ void fs_load_x(const float* x, uintx4f (&v)[FS_XI], int n, int h0, int w0, int H, int W, int tid) {
     const unsigned S = (unsigned)(H * W);
     const unsigned OOB = 0xFFFFFFF0u;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)n * 8 * S), 0, 8u * S * 4u, 0x00020000);
     constexpr int qw = FS_WEXT / 4;
-    for (int f = tid; f < 8 * FS_XR * qw; f += 256) {
+#pragma unroll
+    for (int i = 0; i < FS_XI; ++i) {
+        const int f = tid + 256 * i;
         const int row = f / qw, quad = f - row * qw;
         const int ch = row / FS_XR, xr = row - ch * FS_XR;
         const int hh = h0 - 1 + xr, ww = w0 - FS_DPAD + 4 * quad;
-        const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+        const bool ok = f < 8 * FS_XR * qw && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
         const unsigned e = ((unsigned)ch * (unsigned)H + (unsigned)hh) * (unsigned)W + (unsigned)ww;
-        const uintx4f v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? e * 4u : OOB, 0, 0);
-        *reinterpret_cast<float4*>(lds + (row * qw + quad) * 4) =
-            make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? e * 4u : OOB, 0, 0);
     }
 }
-
+__device__ __forceinline__ void fs_store_x(float* lds, const uintx4f (&v)[FS_XI], int tid) {
+#pragma unroll
+    for (int i = 0; i < FS_XI; ++i) {
+        const int f = tid + 256 * i;
+        if (f < 8 * FS_XR * (FS_WEXT / 4))
+            *reinterpret_cast<float4*>(lds + f * 4) =
+                make_float4(__uint_as_float(v[i][0]), __uint_as_float(v[i][1]), __uint_as_float(v[i][2]), __uint_as_float(v[i][3]));
+    }
+}
 // ---------------------------------------------------------------------------------------------------------------------
 // [G; s]: partial[wg][tile][256] accumulator fragments (tile (t, u), t <= u: rows 16t.., columns 16u..)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -88,12 +99,19 @@ __global__ __launch_bounds__(256, 2) void fs_gram_kernel(const FsGramP p) {
     for (int i = 0; i < FS_NTILE; ++i) acc[i] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
     const int wq = p.W >> 6, hq = p.H >> 3;
-    for (int b = blockIdx.x; b < p.nblocks; b += gridDim.x) {
+    // the next block's tile is requested into registers before this block's MFMAs and written to LDS after them
+    uintx4f xv[FS_XI];
+    auto request = [&](int b) __attribute__((always_inline)) {
         const int n = b / (hq * wq), rem = b - n * (hq * wq);
-        const int h0 = (rem / wq) * 8, w0 = (rem % wq) * 64;
+        fs_load_x(p.x, xv, n, (rem / wq) * 8, (rem % wq) * 64, p.H, p.W, tid);
+    };
+    if ((int)blockIdx.x < p.nblocks) request(blockIdx.x);
+    for (int b = blockIdx.x; b < p.nblocks; b += gridDim.x) {
         __syncthreads();                                   // everybody is done with the previous block's tile
-        fs_stage_x(p.x, lds, n, h0, w0, p.H, p.W, tid);
+        fs_store_x(lds, xv, tid);
         __syncthreads();
+        if (b + (int)gridDim.x < p.nblocks) request(b + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);                 // (the compiler would sink the requests to behind the MFMAs)
 #pragma unroll 1
         for (int r = 0; r < 8; ++r) {
 #pragma unroll
