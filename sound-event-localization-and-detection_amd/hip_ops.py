@@ -1950,7 +1950,29 @@ class ConvBnReluPoolFn(torch.autograd.Function):
         k = tuple(ws[0].shape[2:])
         desc = make_conv_desc(tuple(x.shape), ws[0].shape[0] * algebra, algebra, k, stride, padding, dilation)
         x = _req(x, "x")
+        # The step's first request for packed weight forms re-packs every registered layer (one launch, ~50 us).  The
+        # input's second moments do not need them: when the no-output path is going to be taken they are gathered on the side
+        # stream WHILE the main stream packs, and joined before BatchNorm is evaluated from them.
+        gws = early = None
+        if (ph == 8 and algebra > 1 and training and _side_enabled() and not kernel_timer.active and _first_stage_nostore(desc) and
+                hcq_pack_floats(desc, 2) > 0):          # (timed steps keep the stage's launches on one stream, in one bracket)
+            if _side["stream"] is None:
+                _side["stream"] = torch.cuda.Stream()
+            st = _side["stream"]
+            gws = torch.empty(_fs_bytes(desc, "gram"), device=x.device, dtype=torch.uint8)
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream())
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                L.check(L.lib().seld_first_stage_gram(ctypes.byref(desc), L.ptr(x), L.ptr(gws), ctypes.c_size_t(gws.numel()),
+                                                      L.current_stream()), "seld_first_stage_gram")
+                early = torch.cuda.Event()
+                early.record(st)
+            gws.record_stream(st)
+            x.record_stream(st)
         wp = hcq_weights.get(desc, 2, ws) if (ph == 8 and algebra > 1) else None
+        if early is not None:
+            torch.cuda.current_stream().wait_event(early)
         nostore = wp is not None and training and _first_stage_nostore(desc)
         stats = new_stats(desc.Cout, x.device) if training and not nostore else None
         ctx.gram = None
@@ -1962,9 +1984,10 @@ class ConvBnReluPoolFn(torch.autograd.Function):
             N, C, Hh, Ww = _y_shape(desc, o)
             stage_timer = _Timed(desc, 0, label="first_stage_fwd(gram+bn+finishing_pool_conv)" if kernel_timer.active else None)
             stage_timer.__enter__()
-            gws = torch.empty(_fs_bytes(desc, "gram"), device=x.device, dtype=torch.uint8)
-            L.check(lib.seld_first_stage_gram(ctypes.byref(desc), L.ptr(x), L.ptr(gws), ctypes.c_size_t(gws.numel()),
-                                              L.current_stream()), "seld_first_stage_gram")
+            if early is None:
+                gws = torch.empty(_fs_bytes(desc, "gram"), device=x.device, dtype=torch.uint8)
+                L.check(lib.seld_first_stage_gram(ctypes.byref(desc), L.ptr(x), L.ptr(gws), ctypes.c_size_t(gws.numel()),
+                                                  L.current_stream()), "seld_first_stage_gram")
             mean = torch.empty(C, device=x.device, dtype=torch.float32)
             invstd = torch.empty(C, device=x.device, dtype=torch.float32)
             wg = torch.empty((C, 72), device=x.device, dtype=torch.float32)
