@@ -1954,8 +1954,10 @@ class ConvBnReluPoolFn(torch.autograd.Function):
         # input's second moments do not need them: when the no-output path is going to be taken they are gathered on the side
         # stream WHILE the main stream packs, and joined before BatchNorm is evaluated from them.
         gws = early = None
-        if (ph == 8 and algebra > 1 and training and _side_enabled() and not kernel_timer.active and _first_stage_nostore(desc) and
-                hcq_pack_floats(desc, 2) > 0):          # (timed steps keep the stage's launches on one stream, in one bracket)
+        if (ph == 8 and algebra > 1 and training and _side_enabled() and not kernel_timer.active and
+                hcq_weights.packed_epoch != hcq_weights.epoch and _first_stage_nostore(desc) and hcq_pack_floats(desc, 2) > 0):
+            # (only when a re-pack is pending -- the two-stream model packs before it forks its branches; timed steps keep the
+            #  stage's launches on one stream, in one bracket)
             if _side["stream"] is None:
                 _side["stream"] = torch.cuda.Stream()
             st = _side["stream"]

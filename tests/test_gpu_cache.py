@@ -240,3 +240,37 @@ def test_plain_backward_on_a_cut_model_is_refused():
     torch.cuda.synchronize()
     assert float(front.abs().max()) > 0
     assert not hasattr(m.seld_block, "_backward_cuts")
+
+
+@pytest.mark.parametrize("name", ["c3w_train", "c4w_train", "c5w_train", "c2w_train"])
+def test_every_config_width_records_and_replays(name):
+    """train.GraphedTrainStep at the widths of configs 2-5 in the DEFAULT mode (side stream, two-queue branches, the first
+    stage's second moments gathered beside the weight-form pack): the capture must close and the replays must follow the
+    eager trajectory.  (The two-stream model once crashed `capture_end` when its branches forked the side stream from a
+    branch stream -- no value test saw it, only the config-5 bench line.)"""
+    T, H = pkg().train, pkg().hip_ops
+    case = dict(next(c for c in MODEL_CASES if c["name"] == name), dropout_perc=0.0, spatial_dropout_rate=0.0)
+
+    def run(graph):
+        torch.manual_seed(3)
+        H.philox.set_offset(0)
+        H.hcq_weights.reset()
+        m = build_model(case).to(DEV).train()
+        opt = T.FlatAdam(m.parameters(), lr=1e-3)
+        x = O.closed_form_input((case["B"], case["input_channels"], case["freq_dim"], case["time_dim"])).to(DEV)
+        target = train_target(case).to(DEV)
+        n_sed = int(case["output_classes"] * 3)
+        losses = []
+        if graph:
+            runner = T.GraphedTrainStep(m, opt, x, target, n_sed, 1.0, 5.0, warmup=1)
+            for _ in range(3):
+                losses.append(float(runner().item()))
+        else:
+            for _ in range(4):
+                losses.append(float(_eager_step(m, opt, x, target, n_sed).item()))
+            losses = losses[1:]                  # the recorded runner's warm-up step is the eager run's first
+        torch.cuda.synchronize()
+        return losses
+    lg, le = run(True), run(False)
+    assert all(np.isfinite(v) for v in lg), lg
+    assert np.allclose(lg, le, rtol=5e-3), (lg, le)
