@@ -571,7 +571,15 @@ __global__ __launch_bounds__(256) void hcq_gw_sum_kernel(const GwSumP p) {
     if (s0 >= s1) return;
     const int w0 = s0 / p.per, w1 = (s1 - 1) / p.per;               // workgroups that hold steps of this job
     floatx4 a = (floatx4){0.f, 0.f, 0.f, 0.f};
-    for (int w = w0; w <= w1; ++w)
+    int w = w0;
+    for (; w + 3 <= w1; w += 4) {                 // four requests in flight, added in workgroup order
+        floatx4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const floatx4*>(p.part + (size_t)(w + k + jb) * p.tile_floats + (size_t)i4 * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a += v[k];
+    }
+    for (; w <= w1; ++w)
         a += *reinterpret_cast<const floatx4*>(p.part + (size_t)(w + jb) * p.tile_floats + (size_t)i4 * 4);
     *reinterpret_cast<floatx4*>(p.red + (size_t)jb * p.tile_floats + (size_t)i4 * 4) = a;
 }

@@ -133,11 +133,18 @@ __global__ __launch_bounds__(256) void linear_gemm48_kernel(const LinP p, int ro
     const int K = TRANS ? p.out_f : p.in_f;
     const int Nn = TRANS ? p.in_f : p.out_f;
     __shared__ __attribute__((aligned(16))) float As[64][KS + 4];       // [row][k]
-    __shared__ __attribute__((aligned(16))) float Bs[KS][64 + 4];       // [k][column]
+    __shared__ __attribute__((aligned(16))) float Bs[KS][64 + 16];      // [k][column]; 80 floats: the four k rows of a
+                                                                        // B-operand read fall into four disjoint bank groups
     const int tid = threadIdx.x;
     const int r0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int tr = (tid >> 4) * 4, tn = (tid & 15) * 4;
-    float acc[4][4] = {};
+    // round 3: the products on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): wave w owns rows 16w .. 16w + 15 of the
+    // tile and its four 16-column tiles.  The VALU version (4 x 4 outputs per thread) spent 1.3 us of FMAs per 48-deep
+    // chunk with one wave per SIMD: 34 us per head layer, the two heads' chains on the critical path of every step.
+    const int lane = tid & 63, wave = tid >> 6;
+    const int fm = lane & 15, fkk = lane >> 4;
+    floatx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
     const int nn = tid & 63, kq = tid >> 6;
     const int kblk = (p.kind == SELD_LIN_REAL) ? KS : (TRANS ? p.OA : p.IA);
     const int nblk = (p.kind == SELD_LIN_REAL) ? Nn : (TRANS ? p.IA : p.OA);
@@ -180,34 +187,27 @@ __global__ __launch_bounds__(256) void linear_gemm48_kernel(const LinP p, int ro
         for (int t = 0; t < 12; ++t) Bs[kq + 4 * t][nn] = rb[t];
         __syncthreads();
         if (k0 + KS < K) fetch(k0 + KS);
+        __builtin_amdgcn_sched_barrier(0);       // the next chunk's requests stay in front of this chunk's products
 #pragma unroll
         for (int k4 = 0; k4 < KS; k4 += 4) {
-            float4 a4[4], b4[4];
+            const float a = As[16 * wave + fm][k4 + fkk];              // A[row m][k]
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(&As[tr + i][k4]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) b4[kk] = *reinterpret_cast<const float4*>(&Bs[k4 + kk][tn]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float a[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    acc[i][0] += a[kk] * b4[kk].x;
-                    acc[i][1] += a[kk] * b4[kk].y;
-                    acc[i][2] += a[kk] * b4[kk].z;
-                    acc[i][3] += a[kk] * b4[kk].w;
-                }
-            }
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[k4 + fkk][16 * j + fm], acc[j], 0, 0, 0);
         }
         __syncthreads();
     }
+    // accumulator register r of tile j: row 16 wave + 4 fkk + r, column 16 j + fm
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 16 * j + fm;
+        const float bv = (bias && n < Nn) ? bias[n] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + tr + i, n = n0 + tn + j;
-            if (r < rows && n < Nn) out[(size_t)r * Nn + n] = acc[i][j] + (bias ? bias[n] : 0.f);
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + 16 * wave + 4 * fkk + r;
+            if (row < rows && n < Nn) out[(size_t)row * Nn + n] = acc[j][r] + bv;
         }
+    }
 }
 
 // dM[z][i][o] = sum over the rows of split z of x[r][i] * dy[r][o]; dB[z][o] = the column sums of dy over the same rows
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int rows, int rows_pe
         }
         __syncthreads();
         if (r0 + 16 < rend) fetch(r0 + 16);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float a[4], b[4];
@@ -279,10 +280,28 @@ template <int KIND>
 __global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, const float* __restrict__ dB, int nz, WPtrsMut dw,
                                    float* __restrict__ dbias) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // tab[a][comp] = b | (sign < 0 ? 16 : 0), or -1: inverse of the block pattern, built once per workgroup (scanning the
+    // pattern per element cost 64 evaluations of block_comp + predicated sums: 15-20 us per layer)
+    __shared__ int tab[64];
+    if (KIND != SELD_LIN_REAL && threadIdx.x < KIND * KIND) {
+        const int a = threadIdx.x / KIND, comp = threadIdx.x - a * KIND;
+        int e = -1;
+        for (int b = 0; b < KIND; ++b) {
+            float sign = 0.f;
+            const int cc = (KIND == SELD_LIN_QUAT) ? block_comp(4, b, a, &sign) : block_comp(8, a, b, &sign);
+            if (cc == comp) e = b | (sign < 0.f ? 16 : 0);
+        }
+        tab[threadIdx.x] = e;
+    }
+    __syncthreads();
     const size_t zs = (size_t)p.in_f * p.out_f;
-    auto at = [&](size_t e) {
+    auto at = [&](size_t e) {                     // the splits in order; all (at most 8) requests in flight together
+        float v[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) v[z] = z < nz ? dM[z * zs + e] : 0.f;
         float t = 0.f;
-        for (int z = 0; z < nz; ++z) t += dM[z * zs + e];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) t += v[z];
         return t;
     };
     const int nw = KIND == SELD_LIN_REAL ? p.in_f * p.out_f : p.IA * p.OA * KIND;
@@ -307,16 +326,14 @@ __global__ void linear_fold_kernel(const LinP p, const float* __restrict__ dM, c
         const int rem = idx - comp * per;
         const int c = rem / p.OA, oo = rem - c * p.OA;
         float total = 0.f;
-        // the block pattern is a compile-time table once A is: 16 / 64 constant (component, sign) pairs, of which this
-        // thread's component takes 4 / 4-8 (a run-time A cost 64 evaluations of block_comp per element: 15 us per layer)
-#pragma unroll
-        for (int a = 0; a < A; ++a)
-#pragma unroll
-            for (int b = 0; b < A; ++b) {
-                float sign = 0.f;
-                const int cc = (KIND == SELD_LIN_QUAT) ? block_comp(4, b, a, &sign) : block_comp(8, a, b, &sign);
-                if (cc == comp) total += sign * at((size_t)(a * p.IA + c) * p.out_f + (size_t)b * p.OA + oo);
-            }
+#pragma unroll 1
+        for (int a = 0; a < A; ++a) {
+            const int e = tab[a * A + comp];             // which output block b of input block a holds +-component `comp`
+            if (e < 0) continue;
+            const int b = e & 15;
+            const float sign = (e & 16) ? -1.f : 1.f;
+            total += sign * at((size_t)(a * p.IA + c) * p.out_f + (size_t)b * p.OA + oo);
+        }
         dw.p[comp][rem] = total;
     }
 }
@@ -353,7 +370,7 @@ extern "C" int seld_hc_linear_fwd(int32_t kind, int32_t rows, int32_t in_feature
 }
 
 // row splits of the weight / bias gradient: at most LIN_SPLITS partial results, added in order by the fold
-static constexpr int LIN_SPLITS = 8;
+static constexpr int LIN_SPLITS = 8;        // linear_fold_kernel's `at` reads exactly this many (or fewer) partials
 static int lin_rows_per_split(int rows) {
     int rps = (rows + LIN_SPLITS - 1) / LIN_SPLITS;
     rps = (rps + 15) / 16 * 16;
