@@ -40,7 +40,8 @@
 // 1+2+4: 550 / 517 (the MFMA floor is 481).  The fragment loads are the largest term, and it is not their bytes, their
 // request count or their latency window that costs: loading the 4 raw components per (pair, tile) and forming the 8 sums
 // in registers (half the bytes and requests, two register stages = a whole pair of k-groups ahead) ran 773 / 745, with
-// three-wave occupancy lost on the TCN layers (177 VGPRs); raised wave priority (s_setprio 1) around each k-group's MFMAs 786 / 786; rotating the chunk order per workgroup (so that workgroups in
+// three-wave occupancy lost on the TCN layers (177 VGPRs) -- and again 757 against 701 once both versions had their requests
+// pinned (HCQ_PIN), for the three-tile shapes only; raised wave priority (s_setprio 1) around each k-group's MFMAs 786 / 786; rotating the chunk order per workgroup (so that workgroups in
 // step do not ask the L2 for the same lines) 751 / 723 against 752 / 722; staging the input from cache-resident
 // addresses 712 against 723.  Left as it is.
 #ifndef HCQ_DBG
