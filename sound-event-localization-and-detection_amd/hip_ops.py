@@ -842,6 +842,30 @@ def run_branches(fa, xa, fb, xb):
     return ya, yb
 
 
+class FanOut2Fn(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (the SED and DOA heads, model.py:473-480): the sum of the two
+    gradients is this library's add kernel on the consumer's stream instead of the autograd engine's ATen add."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        ga, gb = _req(ga, "ga"), _req(gb, "gb")
+        out = torch.empty_like(ga)
+        L.check(L.lib().seld_add(L.ptr(ga), L.ptr(gb), ctypes.c_int64(ga.numel()), L.ptr(out), L.current_stream()), "seld_add")
+        return out
+
+
+def fan_out2(x):
+    if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
+        return x, x
+    return FanOut2Fn.apply(x)
+
+
 def _drop_kernel_choice_caches():
     hcq_weights.reset()
     _fs_cache.clear()

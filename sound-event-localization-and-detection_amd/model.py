@@ -443,7 +443,8 @@ class SELD_Model(nn.Module):
         else:
             x = self.seld_block(x)
         # the two classifier heads are independent chains of small-grid kernels: two queues (hip_ops.run_branches)
-        return H.run_branches(self.sed, x, self.doa, x)
+        xa, xb = H.fan_out2(x)
+        return H.run_branches(self.sed, xa, self.doa, xb)
 
     def calculate_receptive_field(self, verbose=0):
         """model.py:482-517."""

@@ -44,8 +44,8 @@ def test_step_launch_budget():
     foreign = {k: v for k, v in names.items() if "seld::" not in k}
     fills = {k: v for k, v in foreign.items() if "fill" in k.lower() or "memset" in k.lower() or "copy" in k.lower()}
     assert not fills, fills                      # no zero-fills, no device copies inside a step
-    # what is left to autograd: the sum of the two classifier heads' input gradients (two dual-quaternion Linear chains on
-    # one tensor; the attention's q / k / v projections are one stacked convolution and leave nothing to add)
-    assert sum(foreign.values()) <= 1, foreign
+    # nothing is left to autograd's own kernels: the attention's q / k / v projections are one stacked convolution, the sum
+    # of the two classifier heads' input gradients is hip_ops.FanOut2Fn (this library's add)
+    assert not foreign, foreign
     assert total <= 200, (total, names.most_common(12))
 
