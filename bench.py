@@ -306,6 +306,10 @@ def main():
         if pick.item() > 0.5:
             step, step_mode = eager_step, "eager"
         step_mode += f" (auto: probe {t_graph * 1e3:.2f} ms recorded / {t_eager * 1e3:.2f} ms eager per step)"
+        # the probes leave the OTHER mode's host state behind (the first replay after eager steps brings the device-resident
+        # step state and the packed-form table up to date: 30-70 ms once): one untimed step of the chosen mode settles it
+        step()
+        torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps between barrier + synchronize; an event after every step gives the per-step
     # times (median) without a host synchronisation inside the region
@@ -347,6 +351,7 @@ def main():
             "metric": "train-step samples/sec (8ch x 128mel x 512T)", "value": round(batch * world * args.steps / elapsed, 3),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm, "ms_per_step": round(ms, 3),
             "ms_per_step_median": round(statistics.median(per_step), 3),
+            "ms_per_step_max": round(max(per_step), 3), "slow_steps": [i for i, v in enumerate(per_step) if v > 1.5 * statistics.median(per_step)],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['name']} train step, F={args.freq} T=512 (U=L={w['U'] * (args.freq // 128)}, SURVEY F3), "
                                    f"batch {batch}/GPU, random-init weights", "global_batch": batch * world,
