@@ -50,6 +50,9 @@
 #ifndef HCQ_PIN
 #define HCQ_PIN 1
 #endif
+#ifndef HCQ_XDMA
+#define HCQ_XDMA 1          // input chunks global -> LDS with LDS-DMA (no staging registers, no ds_write), hcq_conv_kernel only
+#endif
 
 namespace seld {
 
@@ -84,6 +87,19 @@ struct HcqP {
 };
 
 typedef unsigned int uintx4h __attribute__((ext_vector_type(4)));
+typedef int int4h __attribute__((ext_vector_type(4)));
+
+// One 16-byte-per-lane LDS-DMA: LDS[lds_addr + 16 * lane ..] <- buffer[voff ..] (zeros when voff is out of range); lanes that
+// are switched off write nothing.  M0 is saved and restored in the statement.  (csrc/hcq_wgrad_grp.hip uses the same.)
+__device__ __forceinline__ void hcq_dma16(unsigned lds_addr, unsigned voff, int4h rsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ int4h hcq_rsrc(const float* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    return (int4h){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
 
 // n / d for 0 <= n < 2^20 with a precomputed 1.0f / d (exact: see hc_conv_vec.hip)
 __device__ __forceinline__ int small_div_h(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
@@ -173,6 +189,31 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
             if (quad >= qw) { quad -= qw; ++row; }
         }
     }
+#if HCQ_XDMA
+    // Input chunks go global -> LDS directly (buffer_load ... lds): the LDS image is linear in the item index (item f at byte
+    // 16 f), so instruction i of wave w fills the contiguous KiB at 16 (256 i + 64 w); no staging registers (28 of them for
+    // the 3x3 layers), no ds_write.  load_x(buf) requests the next chunk into `buf`; store_x waits for the wave's requests.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    int4h xrs = hcq_rsrc(p.src, src_bytes);
+    int xchunk = 0;                                    // chunks requested so far
+    int xbuf = 0;                                      // buffer the next request fills
+    auto load_x = [&]() __attribute__((always_inline)) {
+        if (xchunk == p.nch) {                         // second source of a pair: same offsets, other tensor
+            xrs = hcq_rsrc(p.src2, src_bytes);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xoff[i] = xoff[i] == OOB ? OOB : xoff[i] - (unsigned)p.nch * xadv;
+        }
+        ++xchunk;
+        const unsigned base = lds0 + (unsigned)xbuf * (unsigned)buf_floats * 4u + 1024u * (unsigned)wave;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            if (xlds[i] >= 0) hcq_dma16(base + 4096u * (unsigned)i, xoff[i], xrs);
+            xoff[i] = xoff[i] == OOB ? OOB : xoff[i] + xadv;
+        }
+        xbuf ^= 1;
+    };
+    auto store_x = [&](int) __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+#else
     floatx4 xr[XI];
     int xchunk = 0;                                    // chunks requested so far
     auto load_x = [&]() __attribute__((always_inline)) {
@@ -196,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
         for (int i = 0; i < XI; ++i)
             if (xlds[i] >= 0) *reinterpret_cast<float4*>(b + xlds[i]) = make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
     };
+#endif
 
     // ---- A-operand addresses: k-group g, this lane's k = 4g + fk -> (ibl, kh, kw); component stride = IBC*KH*wext ----
     int aoff[NG];
@@ -315,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void hcq_conv_kernel(const HcqP p) {
                     // keep the request HERE: between two scheduling barriers the compiler moves loads towards their use
                     // (register pressure), i.e. to the end of this k-group -- a few MFMAs ahead of the wait instead of
                     // seven forms
-                    if (HCQ_PIN && NT >= 3) __builtin_amdgcn_sched_barrier(0);     // (two-tile shapes: 16 more registers, a wave less)
+                    if (HCQ_PIN && (NT >= 3 || HCQ_XDMA)) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (!last && !(HCQ_DBG & 2)) xforms(raw, gm[gst ^ 1]);
